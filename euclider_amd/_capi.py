@@ -1,0 +1,93 @@
+"""ctypes binding of include/euclider_amd.h (libeuclider_amd.so, built in-tree by csrc/Makefile).
+
+The library is the product; this module only declares its symbols.  There is no Python or CPU
+implementation of the trace path: if the shared library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libeuclider_amd.so")
+
+EU_OK = 0
+EU_ERR_INVALID_ARGUMENT = -1
+EU_ERR_PARSE = -2
+EU_ERR_NO_DEVICE = -3
+EU_ERR_HIP = -4
+EU_ERR_CAPACITY = -5
+EU_ERR_TEXTURE = -6
+
+
+class Camera(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("fov_deg", C.c_uint32), ("max_depth", C.c_uint32), ("reserved", C.c_uint32),
+                ("location", C.c_double * 4), ("forward", C.c_double * 4), ("up", C.c_double * 4),
+                ("left", C.c_double * 4)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
+                ("time_ms", C.c_uint64), ("debug_crosshair", C.c_int32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("bg_samples", C.c_uint64), ("nan_pixels", C.c_uint64), ("errors", C.c_uint64)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_entities", C.c_uint32), ("n_shape_ops", C.c_uint32), ("n_leaves", C.c_uint32),
+                ("n_materials", C.c_uint32), ("n_surfaces", C.c_uint32), ("n_color_ops", C.c_uint32),
+                ("n_textures", C.c_uint32), ("hit_cap", C.c_uint32), ("list_depth", C.c_uint32),
+                ("flat_bytes", C.c_uint32)]
+
+
+TEXTURE_LOADER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                             C.POINTER(C.c_void_p))
+
+
+class LoadOpts(C.Structure):
+    _fields_ = [("load_texture", TEXTURE_LOADER), ("user", C.c_void_p), ("random_seed", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+# every symbol include/euclider_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "eu_alloc": (C.c_void_p, [C.c_size_t]),
+    "eu_free": (None, [C.c_void_p]),
+    "eu_scene_from_json": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(LoadOpts), C.POINTER(C.c_void_p), C.c_char_p,
+                                      C.c_size_t]),
+    "eu_scene_free": (None, [C.c_void_p]),
+    "eu_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+    "eu_scene_default_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
+    "eu_scene_flat": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "eu_device_count": (C.c_int, []),
+    "eu_renderer_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "eu_renderer_destroy": (None, [C.c_void_p]),
+    "eu_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "eu_pack_rgb_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "eu_renderer_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "eu_renderer_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "eu_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
+                            C.POINTER(Stats)]),
+    "eu_trace_screen_point": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_double)]),
+    "eu_selftest_math": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "eu_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C euclider_amd/csrc` (or __graft_entry__.build()); "
+                              "there is no fallback implementation" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

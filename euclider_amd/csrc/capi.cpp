@@ -1,0 +1,64 @@
+/*
+ * capi.cpp -- scene half of the C ABI (include/euclider_amd.h): parse, flatten, inspect.
+ * The render half lives in renderer.hip.  Nothing here traces rays.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/euclider_amd.h"
+#include "scene_host.hpp"
+
+using namespace euclider;
+
+static void set_err(char *err, size_t errlen, const std::string &msg) {
+    if (err && errlen) snprintf(err, errlen, "%s", msg.c_str());
+}
+
+extern "C" void *eu_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+extern "C" void eu_free(void *p) { free(p); }
+extern "C" const char *eu_version(void) { return "euclider_amd 0.1 (gfx950)"; }
+
+extern "C" int eu_scene_from_json(const char *json, size_t len, const eu_load_opts *opts, eu_scene **out, char *err, size_t errlen) {
+    if (!json || !out) return EU_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    try {
+        Parser parser = Parser::make_default(opts);
+        auto universe = parser.parse(json, len);
+        eu_scene *s = new eu_scene();
+        s->universe = universe;
+        s->flat = flatten(*universe);
+        *out = s;
+        return EU_OK;
+    } catch (const ParserError &e) {
+        set_err(err, errlen, e.what());
+        return EU_ERR_PARSE;
+    } catch (const std::bad_alloc &) {
+        set_err(err, errlen, "out of memory");
+        return EU_ERR_PARSE;
+    } catch (...) {
+        set_err(err, errlen, "unexpected failure while loading the scene");
+        return EU_ERR_PARSE;
+    }
+}
+
+extern "C" void eu_scene_free(eu_scene *s) { delete s; }
+
+extern "C" int eu_scene_get_info(const eu_scene *s, eu_scene_info *info) {
+    if (!s || !info) return EU_ERR_INVALID_ARGUMENT;
+    *info = s->flat.info;
+    return EU_OK;
+}
+
+extern "C" int eu_scene_default_camera(const eu_scene *s, eu_camera *out) {
+    if (!s || !out) return EU_ERR_INVALID_ARGUMENT;
+    *out = s->universe->camera;
+    return EU_OK;
+}
+
+extern "C" const void *eu_scene_flat(const eu_scene *s, size_t *bytes) {
+    if (!s) return nullptr;
+    if (bytes) *bytes = s->flat.words.size() * 8;
+    return s->flat.words.data();
+}

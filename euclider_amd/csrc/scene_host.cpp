@@ -1,0 +1,945 @@
+/*
+ * scene_host.cpp -- JSON scene loader, universe constructors and flattener (host only).
+ * See scene_host.hpp.  Citations: file:line under /root/reference/src/.
+ */
+#include "scene_host.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "eu_math.h"
+
+namespace euclider {
+
+/* ------------------------------------------------------------------ errors */
+const char *ParserError::kind_name(Kind k) {
+    switch (k) {
+    case NoDeserializer: return "NoDeserializer";
+    case SyntaxError: return "SyntaxError";
+    case MissingType: return "MissingType";
+    case InvalidConstructor: return "InvalidConstructor";
+    case MissingField: return "MissingField";
+    case TypeMismatch: return "TypeMismatch";
+    default: return "CustomError";
+    }
+}
+[[noreturn]] static void fail(ParserError::Kind k, const std::string &d) { throw ParserError{k, d}; }
+
+/* ------------------------------------------------------------------ JSON */
+namespace {
+struct JsonReader {
+    const char *s; size_t n, p = 0;
+    [[noreturn]] void err(const char *what) { fail(ParserError::SyntaxError, std::string("Invalid JSON file. Please, check the syntax. (") + what + " at byte " + std::to_string(p) + ")"); }
+    void ws() { while (p < n && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) p++; }
+    bool lit(const char *w) { size_t l = strlen(w); if (p + l <= n && !memcmp(s + p, w, l)) { p += l; return true; } return false; }
+    Json value(int depth) {
+        if (depth > 256) err("nesting too deep");
+        ws();
+        if (p >= n) err("unexpected end");
+        Json j;
+        char c = s[p];
+        if (c == '{') {
+            p++; j.type = Json::Object; ws();
+            if (p < n && s[p] == '}') { p++; return j; }
+            for (;;) {
+                ws();
+                if (p >= n || s[p] != '"') err("expected string key");
+                std::string k = string();
+                ws();
+                if (p >= n || s[p] != ':') err("expected ':'");
+                p++;
+                j.obj.emplace_back(std::move(k), value(depth + 1));
+                ws();
+                if (p < n && s[p] == ',') { p++; continue; }
+                if (p < n && s[p] == '}') { p++; return j; }
+                err("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            p++; j.type = Json::Array; ws();
+            if (p < n && s[p] == ']') { p++; return j; }
+            for (;;) {
+                j.arr.push_back(value(depth + 1));
+                ws();
+                if (p < n && s[p] == ',') { p++; continue; }
+                if (p < n && s[p] == ']') { p++; return j; }
+                err("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { j.type = Json::String; j.str = string(); return j; }
+        if (lit("true")) { j.type = Json::Bool; j.b = true; return j; }
+        if (lit("false")) { j.type = Json::Bool; j.b = false; return j; }
+        if (lit("null")) { j.type = Json::Null; return j; }
+        if (c == '-' || (c >= '0' && c <= '9')) {
+            size_t q = p;
+            if (s[q] == '-') q++;
+            if (q >= n || !(s[q] >= '0' && s[q] <= '9')) err("bad number");
+            while (q < n && ((s[q] >= '0' && s[q] <= '9') || s[q] == '.' || s[q] == 'e' || s[q] == 'E' || s[q] == '+' || s[q] == '-')) q++;
+            std::string tok(s + p, q - p);
+            char *end = nullptr;
+            j.num = strtod(tok.c_str(), &end);
+            if (!end || *end) err("bad number");
+            j.type = Json::Number;
+            p = q;
+            return j;
+        }
+        err("unexpected character");
+    }
+    std::string string() {
+        std::string out;
+        p++;
+        while (p < n && s[p] != '"') {
+            char c = s[p++];
+            if (c == '\\') {
+                if (p >= n) err("bad escape");
+                char e = s[p++];
+                switch (e) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case '/': out += '/'; break; case '\\': out += '\\'; break; case '"': out += '"'; break;
+                case 'u': {
+                    if (p + 4 > n) err("bad \\u escape");
+                    unsigned cp = (unsigned)strtoul(std::string(s + p, 4).c_str(), nullptr, 16);
+                    p += 4;
+                    if (cp < 0x80) out += (char)cp;
+                    else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                    else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                    break;
+                }
+                default: err("bad escape");
+                }
+            } else out += c;
+        }
+        if (p >= n) err("unterminated string");
+        p++;
+        return out;
+    }
+};
+}  // namespace
+
+Json Json::parse(const char *text, size_t len) {
+    JsonReader r{text, len};
+    Json j = r.value(0);
+    r.ws();
+    if (r.p != len) r.err("trailing characters");
+    return j;
+}
+const Json *Json::get(const std::string &key) const {
+    for (auto &kv : obj) if (kv.first == key) return &kv.second;
+    return nullptr;
+}
+std::string Json::brief() const {
+    switch (type) {
+    case Null: return "null";
+    case Bool: return b ? "true" : "false";
+    case Number: { char buf[64]; snprintf(buf, sizeof buf, "%g", num); return buf; }
+    case String: return "\"" + str + "\"";
+    case Array: return "[...]";
+    default: { std::string s = "{"; for (auto &kv : obj) { s += "\"" + kv.first + "\": ..."; break; } return s + "}"; }
+    }
+}
+
+/* ------------------------------------------------------------------ vectors (nalgebra 0.8.2; x -> w order) */
+static double v_dot(int D, const double *a, const double *b) { double s = a[0] * b[0]; for (int i = 1; i < D; i++) s = s + a[i] * b[i]; return s; }
+static double v_nsq(int D, const double *a) { return v_dot(D, a, a); }
+static void v_normalize(int D, const double *a, double *o) { double n = sqrt(v_nsq(D, a)); for (int i = 0; i < D; i++) o[i] = a[i] / n; }
+
+/* ------------------------------------------------------------------ shapes */
+ShapePtr VoidShape_new(int dim) { auto s = std::make_shared<Shape>(); s->kind = Shape::VoidShape; s->dim = dim; return s; }
+
+ShapePtr Sphere_new(int dim, const double *center, double radius) {           /* shape.rs:643-649 */
+    auto s = std::make_shared<Shape>(); s->kind = Shape::Sphere; s->dim = dim;
+    for (int i = 0; i < dim; i++) s->a[i] = center[i];
+    s->r = radius;
+    return s;
+}
+ShapePtr Hyperplane_new(int dim, const double *normal, double constant) {     /* shape.rs:750-759 */
+    if (!(v_nsq(dim, normal) > 0.0)) fail(ParserError::CustomError, "Cannot have a normal with length of 0.");
+    auto s = std::make_shared<Shape>(); s->kind = Shape::Hyperplane; s->dim = dim;
+    for (int i = 0; i < dim; i++) s->a[i] = normal[i];
+    s->r = constant;
+    return s;
+}
+ShapePtr Hyperplane_new_with_point(int dim, const double *normal, const double *point) {   /* shape.rs:761-766 */
+    double constant = -v_dot(dim, normal, point);
+    return Hyperplane_new(dim, normal, constant);
+}
+ShapePtr Hyperplane_new_with_vectors(const double *a, const double *b, const double *point) {   /* shape.rs:768-776 */
+    double n[MAXD] = {0, 0, 0, 0};
+    n[0] = a[1] * b[2] - a[2] * b[1];
+    n[1] = a[2] * b[0] - a[0] * b[2];
+    n[2] = a[0] * b[1] - a[1] * b[0];
+    return Hyperplane_new_with_point(3, n, point);
+}
+ShapePtr HalfSpace_new(const ShapePtr &plane, double sign) {                  /* shape.rs:828-835 */
+    if (!plane || plane->kind != Shape::Hyperplane)
+        fail(ParserError::CustomError, std::string("Invalid type, expected a `Hyperplane") + (plane && plane->dim == 4 ? "4" : "3") + "`.");
+    auto s = std::make_shared<Shape>(); s->kind = Shape::HalfSpace; s->dim = plane->dim;
+    for (int i = 0; i < plane->dim; i++) s->a[i] = plane->a[i];
+    s->r = plane->r;
+    s->signum = sign / fabs(sign);
+    return s;
+}
+ShapePtr HalfSpace_new_with_point(const ShapePtr &plane, const double *point) {   /* shape.rs:837-841 */
+    if (!plane || plane->kind != Shape::Hyperplane)
+        fail(ParserError::CustomError, std::string("Invalid type, expected a `Hyperplane") + (plane && plane->dim == 4 ? "4" : "3") + "`.");
+    double identifier = v_dot(plane->dim, plane->a, point) + plane->r;
+    return HalfSpace_new(plane, identifier);
+}
+ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op) {   /* shape.rs:523-545: left fold */
+    if (shapes.size() < 2) fail(ParserError::CustomError, "2 or more `Shape`s are needed to construct a `ComposableShape`.");
+    ShapePtr result = shapes[0];
+    for (size_t i = 1; i < shapes.size(); i++) {
+        auto c = std::make_shared<Shape>(); c->kind = Shape::ComposableShape; c->dim = shapes[0]->dim;
+        c->operation = op; c->sa = result; c->sb = shapes[i];
+        result = c;
+    }
+    return result;
+}
+static ShapePtr box_of_halfspaces(int D, const double *center, const double *abc) {
+    double half[MAXD];
+    for (int i = 0; i < D; i++) half[i] = abc[i] / 2.0;
+    double axis[MAXD][MAXD] = {{0}};
+    for (int i = 0; i < D; i++) axis[i][i] = 1.0;
+    std::vector<ShapePtr> shapes;
+    for (int ax = 0; ax < D; ax++) for (int neg = 0; neg < 2; neg++) {
+        double off[MAXD], pt[MAXD];
+        for (int i = 0; i < D; i++) off[i] = axis[ax][i] * half[i];            /* x * half_abc is component-wise */
+        if (neg) for (int i = 0; i < D; i++) off[i] = -off[i];
+        for (int i = 0; i < D; i++) pt[i] = center[i] + off[i];                /* na::translate(&v, &center) */
+        ShapePtr plane;
+        if (D == 3) {                                                          /* d3/entity/shape.rs:22-63 */
+            const double *va = (ax == 0) ? axis[1] : axis[0];
+            const double *vb = (ax == 2) ? axis[1] : axis[2];
+            plane = Hyperplane_new_with_vectors(va, vb, pt);
+        } else {                                                               /* d4/entity/shape.rs:25-72 */
+            double nn[MAXD];
+            v_normalize(D, axis[ax], nn);
+            plane = Hyperplane_new_with_point(D, nn, pt);
+        }
+        shapes.push_back(HalfSpace_new_with_point(plane, center));
+    }
+    return ComposableShape_of(shapes, SetOperation::Intersection);
+}
+ShapePtr HalfSpace_cuboid(const double *center, const double *abc) { return box_of_halfspaces(3, center, abc); }
+ShapePtr HalfSpace_hypercuboid(const double *center, const double *abcd) { return box_of_halfspaces(4, center, abcd); }
+
+ShapePtr Cylinder_new(int dim, const double *center, const double *direction, double radius) {   /* shape.rs:893-904 */
+    if (!(v_nsq(dim, direction) > 0.0)) fail(ParserError::CustomError, "Cannot have a direction with length of 0.");
+    if (!(radius > 0.0)) fail(ParserError::CustomError, "The radius must be positive.");
+    auto s = std::make_shared<Shape>(); s->kind = Shape::Cylinder; s->dim = dim;
+    for (int i = 0; i < dim; i++) s->a[i] = center[i];
+    v_normalize(dim, direction, s->b);
+    s->r = radius;
+    return s;
+}
+ShapePtr Cylinder_new_with_height(int dim, const double *center, const double *direction, double radius, double height) {   /* shape.rs:906-927 */
+    double nd[MAXD], pt[MAXD];
+    v_normalize(dim, direction, nd);
+    double half_height = height / (1.0 + 1.0);
+    std::vector<ShapePtr> shapes;
+    shapes.push_back(Cylinder_new(dim, center, direction, radius));
+    for (int i = 0; i < dim; i++) pt[i] = center[i] + nd[i] * half_height;
+    shapes.push_back(HalfSpace_new_with_point(Hyperplane_new_with_point(dim, nd, pt), center));
+    double neg_half = -half_height;
+    for (int i = 0; i < dim; i++) pt[i] = center[i] + nd[i] * neg_half;
+    shapes.push_back(HalfSpace_new_with_point(Hyperplane_new_with_point(dim, nd, pt), center));
+    return ComposableShape_of(shapes, SetOperation::Intersection);
+}
+
+/* ------------------------------------------------------------------ misc constructors */
+eu_camera default_camera(int dim, const double *loc) {   /* d3/entity/camera.rs:42-52, d4/entity/camera.rs:47-58 */
+    eu_camera c;
+    memset(&c, 0, sizeof c);
+    c.dim = dim;
+    if (loc) for (int i = 0; i < dim; i++) c.location[i] = loc[i];
+    c.forward[0] = 1.0;
+    c.up[2] = 1.0;
+    c.left[1] = 1.0;
+    c.fov_deg = 90;
+    c.max_depth = 10;
+    return c;
+}
+
+/* palette 0.2.1 Hsv -> Rgb with RgbHue::to_positive_degrees (UNVERIFIED third-party semantics) */
+void rgba_from_hsva(double hue, double saturation, double value, double alpha, double *out) {
+    double deg = hue;
+    if (fabs(deg) < 1.0e9) {
+        while (deg >= 360.0) deg = deg - 360.0;
+        while (deg < 0.0) deg = deg + 360.0;
+    }
+    double c = value * saturation;
+    double h = deg / 60.0;
+    double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
+    double m = value - c;
+    double r, g, b;
+    if (h >= 0.0 && h < 1.0) { r = c; g = x; b = 0.0; }
+    else if (h >= 1.0 && h < 2.0) { r = x; g = c; b = 0.0; }
+    else if (h >= 2.0 && h < 3.0) { r = 0.0; g = c; b = x; }
+    else if (h >= 3.0 && h < 4.0) { r = 0.0; g = x; b = c; }
+    else if (h >= 4.0 && h < 5.0) { r = x; g = 0.0; b = c; }
+    else { r = c; g = 0.0; b = x; }
+    out[0] = r + m; out[1] = g + m; out[2] = b + m; out[3] = alpha;
+}
+
+/* deterministic stand-in for textures the reference repository does not ship
+ * (resources/universe_dim.jpg, .MISSING_LARGE_BLOBS) */
+void procedural_uv_grid(uint32_t w, uint32_t h, std::vector<uint8_t> &rgba) {
+    rgba.resize((size_t)w * h * 4);
+    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {
+        uint8_t *p = &rgba[((size_t)y * w + x) * 4];
+        if (x % 64 == 0 || y % 64 == 0) { p[0] = 255; p[1] = 255; p[2] = 255; p[3] = 255; continue; }
+        p[0] = (uint8_t)(x * 255u / (w > 1 ? w - 1 : 1));
+        p[1] = (uint8_t)(y * 255u / (h > 1 ? h - 1 : 1));
+        p[2] = (uint8_t)(64u + 128u * (((x / 32) + (y / 32)) % 2));
+        p[3] = 255;
+    }
+}
+
+/* ------------------------------------------------------------------ expressions (meval 0.1.0 subset) */
+namespace {
+const char *FN_NAMES[EU_FN_COUNT] = {"sqrt", "abs", "floor", "ceil", "min", "max", "sin", "cos", "tan", "asin", "acos", "atan", "atan2", "signum"};
+const int FN_ARITY[EU_FN_COUNT] = {1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 2, 1};
+
+/* Recursive descent emitting RPN directly.  Precedence (meval's shunting yard, UNVERIFIED):
+ * + - (left) < * / % (left) < unary +- < ^ (right). */
+struct ExprCompiler {
+    const std::string &s; size_t p = 0; std::vector<Expr::Tok> &out; bool ok = true;
+    void ws() { while (p < s.size() && isspace((unsigned char)s[p])) p++; }
+    void emit(uint32_t op, uint32_t arg = 0, double k = 0.0, const std::string &v = "") { out.push_back({op, arg, k, v}); }
+    void atom() {
+        ws();
+        if (p >= s.size()) { ok = false; return; }
+        char c = s[p];
+        if (c == '(') { p++; expr(); ws(); if (p < s.size() && s[p] == ')') p++; else ok = false; return; }
+        if (isdigit((unsigned char)c) || c == '.') {
+            const char *b = s.c_str() + p; char *e = nullptr;
+            double v = strtod(b, &e);
+            if (e == b) { ok = false; return; }
+            p += (size_t)(e - b);
+            emit(EU_RPN_CONST, 0, v);
+            return;
+        }
+        if (isalpha((unsigned char)c) || c == '_') {
+            std::string name;
+            while (p < s.size() && (isalnum((unsigned char)s[p]) || s[p] == '_')) name += s[p++];
+            ws();
+            if (p < s.size() && s[p] == '(') {
+                int fn = -1;
+                for (int i = 0; i < (int)EU_FN_COUNT; i++) if (name == FN_NAMES[i]) fn = i;
+                if (fn < 0) { ok = false; return; }
+                p++;
+                expr(); ws();
+                if (FN_ARITY[fn] == 2) { if (p < s.size() && s[p] == ',') { p++; expr(); ws(); } else { ok = false; return; } }
+                if (p < s.size() && s[p] == ')') p++; else { ok = false; return; }
+                emit(EU_RPN_FN, (uint32_t)fn);
+                return;
+            }
+            if (name == "pi") { emit(EU_RPN_CONST, 0, 3.14159265358979323846264338327950288); return; }
+            if (name == "e") { emit(EU_RPN_CONST, 0, 2.71828182845904523536028747135266250); return; }
+            emit(EU_RPN_VAR, 0, 0.0, name);
+            return;
+        }
+        ok = false;
+    }
+    void power() { atom(); ws(); if (ok && p < s.size() && s[p] == '^') { p++; unary(); emit(EU_RPN_POW); } }
+    void unary() {
+        ws();
+        if (p < s.size() && s[p] == '-') { p++; unary(); emit(EU_RPN_NEG); return; }
+        if (p < s.size() && s[p] == '+') { p++; unary(); return; }
+        power();
+    }
+    void term() {
+        unary();
+        for (;;) {
+            ws();
+            if (!ok || p >= s.size() || (s[p] != '*' && s[p] != '/' && s[p] != '%')) return;
+            char c = s[p++];
+            unary();
+            emit(c == '*' ? EU_RPN_MUL : c == '/' ? EU_RPN_DIV : EU_RPN_REM);
+        }
+    }
+    void expr() {
+        term();
+        for (;;) {
+            ws();
+            if (!ok || p >= s.size() || (s[p] != '+' && s[p] != '-')) return;
+            char c = s[p++];
+            term();
+            emit(c == '+' ? EU_RPN_ADD : EU_RPN_SUB);
+        }
+    }
+};
+}  // namespace
+
+Expr Expr::from_str(const std::string &src) {
+    Expr e; e.source = src;
+    ExprCompiler c{src, 0, e.rpn};
+    c.expr(); c.ws();
+    if (!c.ok || c.p != src.size() || e.rpn.empty())
+        fail(ParserError::CustomError, "Invalid component transformation expression `" + src + "`.");
+    return e;
+}
+int Expr::stack_depth() const {
+    int d = 0, mx = 0;
+    for (auto &t : rpn) {
+        switch (t.op) {
+        case EU_RPN_CONST: case EU_RPN_VAR: d++; break;
+        case EU_RPN_NEG: break;
+        case EU_RPN_FN: d -= FN_ARITY[t.arg] - 1; break;
+        default: d--; break;
+        }
+        if (d > mx) mx = d;
+    }
+    return mx;
+}
+
+/* ------------------------------------------------------------------ parser (scene.rs:554-1478) */
+namespace {
+enum class T { F, U8, U32, Str, Point, Vector, Rgba, Entity, Shape, Material, Surface, SetOperation, Expr,
+               LinearTransformation, UVFn, Texture, MappedTexture, ReflectionRatio, ReflectionDirection,
+               ThresholdDirection, SurfaceColor, BlendFunction, Camera, Environment };
+struct Ty { T t; int dim; bool vec; };
+static Ty ty(T t, int dim = 0, bool vec = false) { return Ty{t, dim, vec}; }
+static std::string ty_name(const Ty &x) {
+    static const char *names[] = {"F", "u8", "u32", "&str", "Point", "Vector", "Rgba<F>", "Entity", "Shape", "Material", "Surface",
+        "SetOperation", "ComponentTransformationExpr", "LinearTransformation", "UVFn", "Texture", "MappedTexture",
+        "ReflectionRatioProvider", "ReflectionDirectionProvider", "ThresholdDirectionProvider", "SurfaceColorProvider",
+        "BlendFunction", "Camera", "Environment"};
+    std::string s = names[(int)x.t];
+    if (x.dim) s += std::to_string(x.dim);
+    if (x.vec) s = "Vec<" + s + ">";
+    return s;
+}
+struct Value {
+    double num = 0.0;
+    std::string str;
+    std::array<double, 4> vec{{0, 0, 0, 0}};
+    std::shared_ptr<void> obj;
+    std::vector<Value> list;
+};
+struct Field { const char *name; Ty type; };
+struct Parser_;
+struct Ctor {
+    std::vector<Field> fields;
+    Ty product;
+    std::function<Value(Parser_ &, std::vector<Value> &)> build;
+};
+template <class X> std::shared_ptr<X> as(const Value &v) { return std::static_pointer_cast<X>(v.obj); }
+template <class X> Value wrap(std::shared_ptr<X> p) { Value v; v.obj = std::move(p); return v; }
+}  // namespace
+
+struct Parser::Impl {};
+
+namespace {
+struct Parser_ {
+    eu_load_opts opts{};
+    uint32_t substituted = 0;
+    std::map<std::string, Ctor> reg;
+
+    void add(std::initializer_list<const char *> names, std::vector<Field> fields, Ty product,
+             std::function<Value(Parser_ &, std::vector<Value> &)> build) {
+        for (auto n : names) reg[n] = Ctor{fields, product, build};
+    }
+
+    std::shared_ptr<Texture> load_texture(const std::string &path, uint32_t kind) {
+        auto t = std::make_shared<Texture>();
+        t->kind = kind; t->path = path;
+        t->rgba = std::make_shared<std::vector<uint8_t>>();
+        uint32_t w = 0, h = 0; uint8_t *px = nullptr;
+        int rc = -1;
+        if (opts.load_texture) rc = opts.load_texture(opts.user, path.c_str(), &w, &h, &px);
+        if (rc == 0 && px && w && h) {
+            t->w = w; t->h = h;
+            t->rgba->assign(px, px + (size_t)w * h * 4);
+            free(px);
+        } else {
+            /* image::open would fail: "Could not load texture" (scene.rs:1053-1068).  The
+             * benchmark scenes reference a file the reference repository does not ship, so
+             * the loader substitutes the documented procedural grid and counts it. */
+            if (px) free(px);
+            t->w = 1024; t->h = 512;
+            procedural_uv_grid(t->w, t->h, *t->rgba);
+            substituted++;
+        }
+        return t;
+    }
+
+    Value field(const Ty &type, const Json &j, const Json &parent) {
+        if (type.vec) {
+            if (j.type != Json::Array) fail(ParserError::TypeMismatch, "Expected an array for `" + ty_name(type) + "`, could not parse from `" + j.brief() + "`.");
+            Value v;
+            Ty inner = type; inner.vec = false;
+            for (auto &e : j.arr) v.list.push_back(field(inner, e, parent));
+            return v;
+        }
+        switch (type.t) {
+        case T::F: {
+            if (j.type != Json::Number) fail(ParserError::TypeMismatch, "Expected `floating point number`, could not parse from `" + j.brief() + "`.");
+            Value v; v.num = j.num; return v;
+        }
+        case T::U8: case T::U32: {
+            double lim = type.t == T::U8 ? 255.0 : 4294967295.0;
+            if (j.type != Json::Number || !(j.num >= 0.0 && j.num <= lim) || j.num != floor(j.num))
+                fail(ParserError::TypeMismatch, std::string("Expected `") + (type.t == T::U8 ? "8-bit unsigned integer" : "32-bit unsigned integer") + "`, could not parse from `" + j.brief() + "`.");
+            Value v; v.num = j.num; return v;
+        }
+        case T::Str: {
+            if (j.type != Json::String) fail(ParserError::TypeMismatch, "Expected `string`, could not parse from `" + j.brief() + "`.");
+            Value v; v.str = j.str; return v;
+        }
+        default: return construct(type, j);
+        }
+    }
+
+    /* deserialize_constructor + deserialize (scene.rs:1430-1464) */
+    Value construct(const Ty &expected, const Json &j) {
+        if (j.type != Json::Object || j.obj.size() != 1)
+            fail(ParserError::InvalidConstructor, "A constructor must be an object containing a single key pointing to either an object or an array.");
+        const std::string &key = j.obj[0].first;
+        const Json &data = j.obj[0].second;
+        auto it = reg.find(key);
+        if (it == reg.end()) fail(ParserError::NoDeserializer, "No deserializer registered for key `" + key + "`.");
+        const Ctor &c = it->second;
+        if (c.product.t != expected.t || c.product.dim != expected.dim)
+            fail(ParserError::TypeMismatch, "The constructor used (`" + key + "`) has an incorrect type for this field. (expected " +
+                                            ty_name(expected) + ", it produces " + ty_name(c.product) + ")");
+        std::vector<Value> args;
+        if (data.type == Json::Object) {
+            for (auto &f : c.fields) {
+                const Json *v = data.get(f.name);
+                if (!v) fail(ParserError::MissingField, "Missing field of type " + ty_name(f.type) + " with key " + f.name + " in `" + key + "`.");
+                args.push_back(field(f.type, *v, j));
+            }
+        } else if (data.type == Json::Array) {
+            size_t i = 0;
+            for (auto &f : c.fields) {
+                if (i >= data.arr.size())
+                    fail(ParserError::MissingField, "Missing field of type " + ty_name(f.type) + " in `" + key + "`. To fix this, add the field at the end of the array.");
+                args.push_back(field(f.type, data.arr[i++], j));
+            }
+        } else {
+            fail(ParserError::InvalidConstructor, "The constructor data may only be an array or an object, received " + data.brief() + " instead.");
+        }
+        return c.build(*this, args);
+    }
+
+    void build_registry();
+};
+
+static const double *vp(const Value &v) { return v.vec.data(); }
+
+void Parser_::build_registry() {
+    for (int d = 3; d <= 4; d++) {
+        std::vector<Field> comps = {{"x", ty(T::F)}, {"y", ty(T::F)}, {"z", ty(T::F)}};
+        if (d == 4) comps.push_back({"w", ty(T::F)});
+        auto mkvec = [d](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < d; i++) v.vec[i] = a[i].num; return v; };
+        std::string P = "Point" + std::to_string(d), V = "Vector" + std::to_string(d);
+        reg[P] = reg[P + "::new"] = Ctor{comps, ty(T::Point, d), mkvec};                      /* scene.rs:620-633 */
+        reg[V] = reg[V + "::new"] = Ctor{comps, ty(T::Vector, d), mkvec};                     /* scene.rs:634-647 */
+    }
+    std::vector<Field> rgba_f = {{"r", ty(T::F)}, {"g", ty(T::F)}, {"b", ty(T::F)}, {"a", ty(T::F)}};
+    add({"Rgba", "Rgba::new"}, rgba_f, ty(T::Rgba), [](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < 4; i++) v.vec[i] = a[i].num; return v; });
+    add({"Rgba::new_u8"}, {{"r", ty(T::U8)}, {"g", ty(T::U8)}, {"b", ty(T::U8)}, {"a", ty(T::U8)}}, ty(T::Rgba),
+        [](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < 4; i++) v.vec[i] = a[i].num / 255.0; return v; });
+    add({"Rgba::from_hsva"}, {{"hue", ty(T::F)}, {"saturation", ty(T::F)}, {"value", ty(T::F)}, {"alpha", ty(T::F)}}, ty(T::Rgba),
+        [](Parser_ &, std::vector<Value> &a) { Value v; rgba_from_hsva(a[0].num, a[1].num, a[2].num, a[3].num, v.vec.data()); return v; });
+    add({"SetOperation", "SetOperation::new"}, {{"name", ty(T::Str)}}, ty(T::SetOperation), [](Parser_ &, std::vector<Value> &a) {   /* scene.rs:774-787 */
+        Value v;
+        if (a[0].str == "Union") v.num = 0; else if (a[0].str == "Intersection") v.num = 1;
+        else if (a[0].str == "Complement") v.num = 2; else if (a[0].str == "SymmetricDifference") v.num = 3;
+        else fail(ParserError::CustomError, "Invalid `SetOperation`: \"" + a[0].str + "\"");
+        return v;
+    });
+    add({"ComponentTransformationExpr", "ComponentTransformationExpr::new"}, {{"expression", ty(T::Str)}, {"inverse_expression", ty(T::Str)}}, ty(T::Expr),
+        [](Parser_ &, std::vector<Value> &a) {                                                /* scene.rs:961-989 */
+            auto e = std::make_shared<ComponentTransformationExpr>();
+            e->expression = Expr::from_str(a[0].str);
+            e->inverse_expression = Expr::from_str(a[1].str);
+            return wrap(e);
+        });
+    add({"uv_sphere_3"}, {{"center", ty(T::Point, 3)}}, ty(T::UVFn, 3), [](Parser_ &, std::vector<Value> &a) {   /* scene.rs:1037-1042 */
+        auto u = std::make_shared<UVFn>(); u->dim = 3; for (int i = 0; i < 3; i++) u->center[i] = a[0].vec[i]; return wrap(u);
+    });
+    add({"uv_derank_4"}, {{"uvfn", ty(T::UVFn, 3)}}, ty(T::UVFn, 4), [](Parser_ &, std::vector<Value> &a) {      /* scene.rs:1044-1049 */
+        auto u = std::make_shared<UVFn>(*as<UVFn>(a[0])); u->dim = 4; return wrap(u);
+    });
+    add({"texture_image_nearest_neighbor"}, {{"path", ty(T::Str)}}, ty(T::Texture), [](Parser_ &p, std::vector<Value> &a) { return wrap(p.load_texture(a[0].str, EU_TEX_NEAREST)); });
+    add({"texture_image_linear"}, {{"path", ty(T::Str)}}, ty(T::Texture), [](Parser_ &p, std::vector<Value> &a) { return wrap(p.load_texture(a[0].str, EU_TEX_LINEAR)); });
+    add({"blend_function_ratio"}, {{"ratio", ty(T::F)}}, ty(T::BlendFunction), [](Parser_ &, std::vector<Value> &a) {
+        auto b = std::make_shared<BlendFunction>(); b->fn = EU_BL_RATIO; b->ratio = a[0].num; return wrap(b);
+    });
+    static const char *blend_names[] = {"over", "inside", "outside", "atop", "xor", "plus", "multiply", "screen", "overlay", "darken",
+                                        "lighten", "dodge", "burn", "hard_light", "soft_light", "difference", "exclusion"};
+    for (uint32_t i = 0; i < 17; i++) {                                                       /* scene.rs:1131-1158 */
+        std::string name = std::string("blend_function_") + blend_names[i];
+        reg[name] = Ctor{{}, ty(T::BlendFunction), [i](Parser_ &, std::vector<Value> &) { auto b = std::make_shared<BlendFunction>(); b->fn = i; return wrap(b); }};
+    }
+
+    for (int d = 3; d <= 4; d++) {
+        const std::string n = std::to_string(d);
+        Ty P = ty(T::Point, d), V = ty(T::Vector, d), SH = ty(T::Shape, d), MAT = ty(T::Material, d), SURF = ty(T::Surface, d), ENT = ty(T::Entity, d);
+        Ty RR = ty(T::ReflectionRatio, d), RD = ty(T::ReflectionDirection, d), TD = ty(T::ThresholdDirection, d), SC = ty(T::SurfaceColor, d);
+        auto N = [&](const char *fmt) { std::string s = fmt; size_t k; while ((k = s.find('#')) != std::string::npos) s.replace(k, 1, n); return s; };
+        auto addn = [&](std::initializer_list<const char *> names, std::vector<Field> f, Ty prod, std::function<Value(Parser_ &, std::vector<Value> &)> b) {
+            for (auto nm : names) reg[N(nm)] = Ctor{f, prod, b};
+        };
+        /* entities, scene.rs:672-738 */
+        addn({"Void#", "Void#::new"}, {{"material", MAT}}, ENT, [](Parser_ &, std::vector<Value> &a) {
+            auto e = std::make_shared<Entity>(); e->material = as<Material>(a[0]); e->shape = VoidShape_new(e->material->dim); return wrap(e); });
+        addn({"Void#::new_with_vacuum"}, {}, ENT, [d](Parser_ &, std::vector<Value> &) {
+            auto e = std::make_shared<Entity>(); e->material = std::make_shared<Material>(); e->material->dim = d; e->shape = VoidShape_new(d); return wrap(e); });
+        addn({"Entity#Impl", "Entity#Impl::new", "Entity#Impl::new_with_surface"}, {{"shape", SH}, {"material", MAT}, {"surface", SURF}}, ENT,
+             [](Parser_ &, std::vector<Value> &a) { auto e = std::make_shared<Entity>(); e->shape = as<Shape>(a[0]); e->material = as<Material>(a[1]); e->surface = as<ComposableSurface>(a[2]); return wrap(e); });
+        addn({"Entity#Impl::new_without_surface"}, {{"shape", SH}, {"material", MAT}}, ENT,
+             [](Parser_ &, std::vector<Value> &a) { auto e = std::make_shared<Entity>(); e->shape = as<Shape>(a[0]); e->material = as<Material>(a[1]); return wrap(e); });
+        /* shapes, scene.rs:742-943 */
+        addn({"VoidShape#", "VoidShape#::new"}, {}, SH, [d](Parser_ &, std::vector<Value> &) { return wrap(VoidShape_new(d)); });
+        addn({"ComposableShape#", "ComposableShape#::new", "ComposableShape#::of"}, {{"shapes", ty(T::Shape, d, true)}, {"operation", ty(T::SetOperation)}}, SH,
+             [](Parser_ &, std::vector<Value> &a) { std::vector<ShapePtr> s; for (auto &v : a[0].list) s.push_back(as<Shape>(v)); return wrap(ComposableShape_of(s, (SetOperation)(int)a[1].num)); });
+        addn({"Sphere#", "Sphere#::new"}, {{"center", P}, {"radius", ty(T::F)}}, SH, [d](Parser_ &, std::vector<Value> &a) { return wrap(Sphere_new(d, vp(a[0]), a[1].num)); });
+        addn({"Hyperplane#", "Hyperplane#::new"}, {{"normal", V}, {"constant", ty(T::F)}}, SH, [d](Parser_ &, std::vector<Value> &a) { return wrap(Hyperplane_new(d, vp(a[0]), a[1].num)); });
+        addn({"Hyperplane#::new_with_point"}, {{"normal", V}, {"point", P}}, SH, [d](Parser_ &, std::vector<Value> &a) { return wrap(Hyperplane_new_with_point(d, vp(a[0]), vp(a[1]))); });
+        if (d == 3)
+            addn({"Hyperplane3::new_with_vectors"}, {{"first", V}, {"second", V}, {"point", P}}, SH, [](Parser_ &, std::vector<Value> &a) { return wrap(Hyperplane_new_with_vectors(vp(a[0]), vp(a[1]), vp(a[2]))); });
+        addn({"HalfSpace#", "HalfSpace#::new"}, {{"plane", SH}, {"sign", ty(T::F)}}, SH, [](Parser_ &, std::vector<Value> &a) { return wrap(HalfSpace_new(as<Shape>(a[0]), a[1].num)); });
+        addn({"HalfSpace#::new_with_point"}, {{"plane", SH}, {"point", P}}, SH, [](Parser_ &, std::vector<Value> &a) { return wrap(HalfSpace_new_with_point(as<Shape>(a[0]), vp(a[1]))); });
+        if (d == 3) addn({"HalfSpace3::cuboid"}, {{"center", P}, {"dimensions", V}}, SH, [](Parser_ &, std::vector<Value> &a) { return wrap(HalfSpace_cuboid(vp(a[0]), vp(a[1]))); });
+        else addn({"HalfSpace4::hypercuboid"}, {{"center", P}, {"dimensions", V}}, SH, [](Parser_ &, std::vector<Value> &a) { return wrap(HalfSpace_hypercuboid(vp(a[0]), vp(a[1]))); });
+        addn({"Cylinder#", "Cylinder#::new"}, {{"center", P}, {"direction", V}, {"radius", ty(T::F)}}, SH,
+             [d](Parser_ &, std::vector<Value> &a) { return wrap(Cylinder_new(d, vp(a[0]), vp(a[1]), a[2].num)); });
+        addn({"Cylinder#::new_with_height"}, {{"center", P}, {"direction", V}, {"radius", ty(T::F)}, {"height", ty(T::F)}}, SH,
+             [d](Parser_ &, std::vector<Value> &a) { return wrap(Cylinder_new_with_height(d, vp(a[0]), vp(a[1]), a[2].num, a[3].num)); });
+        /* materials, scene.rs:947-1033 */
+        addn({"Vacuum#", "Vacuum#::new"}, {}, MAT, [d](Parser_ &, std::vector<Value> &) { auto m = std::make_shared<Material>(); m->dim = d; return wrap(m); });
+        addn({"ComponentTransformation#", "ComponentTransformation#::new"}, {{"expressions", ty(T::Expr, 0, true)}}, ty(T::LinearTransformation, d),
+             [](Parser_ &, std::vector<Value> &a) { auto t = std::make_shared<ComponentTransformation>(); for (auto &v : a[0].list) t->expressions.push_back(*as<ComponentTransformationExpr>(v)); return wrap(t); });
+        addn({"LinearSpace#", "LinearSpace#::new"}, {{"legend", ty(T::Str)}, {"transformations", ty(T::LinearTransformation, d, true)}}, MAT,
+             [d](Parser_ &, std::vector<Value> &a) {
+                 auto m = std::make_shared<Material>(); m->kind = Material::LinearSpace; m->dim = d; m->legend = a[0].str;
+                 for (auto &v : a[1].list) m->transformations.push_back(as<ComponentTransformation>(v));
+                 return wrap(m);
+             });
+        /* textures + surfaces, scene.rs:1075-1335 */
+        addn({"MappedTextureImpl#", "MappedTextureImpl#::new"}, {{"uvfn", ty(T::UVFn, d)}, {"texture", ty(T::Texture)}}, ty(T::MappedTexture, d),
+             [d](Parser_ &, std::vector<Value> &a) { auto m = std::make_shared<MappedTexture>(); m->dim = d; m->uvfn = as<UVFn>(a[0]); m->texture = as<Texture>(a[1]); return wrap(m); });
+        addn({"ComposableSurface#", "ComposableSurface#::new"},
+             {{"reflection_ratio", RR}, {"reflection_direction", RD}, {"threshold_direction", TD}, {"surface_color", SC}}, SURF,
+             [](Parser_ &, std::vector<Value> &a) {
+                 auto s = std::make_shared<ComposableSurface>();
+                 s->reflection_ratio = as<ReflectionRatio>(a[0]); s->reflection_direction = as<ReflectionDirection>(a[1]);
+                 s->threshold_direction = as<ThresholdDirection>(a[2]); s->surface_color = as<SurfaceColor>(a[3]);
+                 return wrap(s);
+             });
+        addn({"surface_color_blend_#"}, {{"source", SC}, {"destination", SC}, {"blend_function", ty(T::BlendFunction)}}, SC,
+             [d](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_BLEND; c->dim = d; c->source = as<SurfaceColor>(a[0]); c->destination = as<SurfaceColor>(a[1]); c->blend = as<BlendFunction>(a[2]); return wrap(c); });
+        addn({"surface_color_illumination_global_#"}, {{"light_color", ty(T::Rgba)}, {"dark_color", ty(T::Rgba)}}, SC,
+             [d](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_ILLUM_GLOBAL; c->dim = d; for (int i = 0; i < 4; i++) { c->c0[i] = a[0].vec[i]; c->c1[i] = a[1].vec[i]; } return wrap(c); });
+        addn({"surface_color_illumination_directional_#"}, {{"direction", V}, {"light_color", ty(T::Rgba)}, {"dark_color", ty(T::Rgba)}}, SC,
+             [d](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_ILLUM_DIR; c->dim = d; for (int i = 0; i < 4; i++) { c->v[i] = a[0].vec[i]; c->c0[i] = a[1].vec[i]; c->c1[i] = a[2].vec[i]; } return wrap(c); });
+        if (d == 3) {
+            addn({"surface_color_perlin_hue_seed_3"}, {{"seed", ty(T::U32)}, {"size", ty(T::F)}, {"speed", ty(T::F)}}, SC,
+                 [](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_PERLIN; c->seed = (uint32_t)a[0].num; c->v[0] = a[1].num; c->v[1] = a[2].num; return wrap(c); });
+            addn({"surface_color_perlin_hue_random_3"}, {{"size", ty(T::F)}, {"speed", ty(T::F)}}, SC,
+                 [](Parser_ &p, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_PERLIN; c->seed = p.opts.random_seed; c->v[0] = a[0].num; c->v[1] = a[1].num; return wrap(c); });
+        }
+        addn({"reflection_ratio_uniform_#"}, {{"ratio", ty(T::F)}}, RR, [](Parser_ &, std::vector<Value> &a) { auto r = std::make_shared<ReflectionRatio>(); r->kind = EU_RATIO_UNIFORM; r->p0 = a[0].num; return wrap(r); });
+        addn({"reflection_ratio_fresnel_#"}, {{"refractive_index_inside", ty(T::F)}, {"refractive_index_outside", ty(T::F)}}, RR,
+             [](Parser_ &, std::vector<Value> &a) { auto r = std::make_shared<ReflectionRatio>(); r->kind = EU_RATIO_FRESNEL; r->p0 = a[0].num; r->p1 = a[1].num; return wrap(r); });
+        addn({"reflection_direction_specular_#"}, {}, RD, [](Parser_ &, std::vector<Value> &) { return wrap(std::make_shared<ReflectionDirection>()); });
+        addn({"threshold_direction_snell_#"}, {{"refractive_index", ty(T::F)}}, TD, [](Parser_ &, std::vector<Value> &a) { auto t = std::make_shared<ThresholdDirection>(); t->kind = EU_THR_SNELL; t->p0 = a[0].num; return wrap(t); });
+        addn({"threshold_direction_identity_#"}, {}, TD, [](Parser_ &, std::vector<Value> &) { auto t = std::make_shared<ThresholdDirection>(); t->kind = EU_THR_IDENTITY; return wrap(t); });
+        addn({"surface_color_uniform_#"}, {{"color", ty(T::Rgba)}}, SC, [d](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_UNIFORM; c->dim = d; for (int i = 0; i < 4; i++) c->c0[i] = a[0].vec[i]; return wrap(c); });
+        addn({"surface_color_texture_#"}, {{"mapped_texture", ty(T::MappedTexture, d)}}, SC, [d](Parser_ &, std::vector<Value> &a) { auto c = std::make_shared<SurfaceColor>(); c->kind = EU_COL_TEXTURE; c->dim = d; c->mapped = as<MappedTexture>(a[0]); return wrap(c); });
+        /* environments + cameras, scene.rs:1339-1408 */
+        addn({"Universe#", "Universe#::new"}, {{"camera", ty(T::Camera, d)}, {"entities", ty(T::Entity, d, true)}, {"background", ty(T::MappedTexture, d)}}, ty(T::Environment),
+             [d](Parser_ &, std::vector<Value> &a) {
+                 auto u = std::make_shared<Universe>(); u->dim = d;
+                 u->camera = *as<eu_camera>(a[0]);
+                 for (auto &v : a[1].list) u->entities.push_back(as<Entity>(v));
+                 u->background = as<MappedTexture>(a[2]);
+                 return wrap(u);
+             });
+        auto cam0 = [d](Parser_ &, std::vector<Value> &) { return wrap(std::make_shared<eu_camera>(default_camera(d, nullptr))); };
+        auto cam1 = [d](Parser_ &, std::vector<Value> &a) { return wrap(std::make_shared<eu_camera>(default_camera(d, vp(a[0])))); };
+        if (d == 3) {
+            addn({"PitchYawCamera3", "PitchYawCamera3::new", "FreeCamera3", "FreeCamera3::new"}, {}, ty(T::Camera, 3), cam0);
+            addn({"PitchYawCamera3::new_with_location", "FreeCamera3::new_with_location"}, {{"location", P}}, ty(T::Camera, 3), cam1);
+        } else {
+            addn({"FreeCamera4", "FreeCamera4::new"}, {}, ty(T::Camera, 4), cam0);
+            addn({"FreeCamera4::new_with_location"}, {{"location", P}}, ty(T::Camera, 4), cam1);
+        }
+    }
+}
+}  // namespace
+
+Parser Parser::make_default(const eu_load_opts *opts) {
+    Parser p;
+    if (opts) p.opts = *opts;
+    return p;
+}
+
+std::shared_ptr<Universe> Parser::parse(const char *json, size_t len) {   /* scene.rs:1466-1478 */
+    Json doc = Json::parse(json, len);
+    Parser_ p;
+    p.opts = opts;
+    p.build_registry();
+    Value v = p.construct(ty(T::Environment), doc);
+    textures_substituted = p.substituted;
+    return as<Universe>(v);
+}
+
+/* ------------------------------------------------------------------ flatten */
+namespace {
+struct Flattener {
+    int D;
+    std::vector<EuShapeOp> ops;
+    std::vector<double> params;
+    std::vector<EuFlatEntity> entities;
+    std::vector<EuFlatMaterial> materials;
+    std::vector<uint64_t> transforms;     /* 8 words each */
+    std::vector<uint64_t> code;
+    std::vector<EuFlatSurface> surfaces;
+    std::vector<EuFlatColorOp> color_ops;
+    std::vector<EuFlatMapped> mapped;
+    std::vector<std::shared_ptr<Texture>> textures;
+    std::vector<std::array<uint8_t, 512>> perlin;
+    std::map<const void *, uint32_t> mat_ids, surf_ids, mapped_ids;
+    uint32_t hit_cap = 0, list_depth = 0, color_depth = 0, rpn_depth = 0, n_leaves = 0;
+
+    /* returns (max list length of the node's stream); tracks the simulated hit-stack */
+    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth) {
+        if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
+        EuShapeOp op{};
+        op.first = (uint16_t)ops.size();
+        uint32_t len = 0;
+        if (s.kind == Shape::ComposableShape) {
+            uint32_t la = emit_shape(*s.sa, base_use, depth);
+            uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1);
+            len = la + lb;
+            uint32_t use = base_use + la + lb + len;       /* inputs + merge output */
+            if (use > hit_cap) hit_cap = use;
+            if (depth + 2 > list_depth) list_depth = depth + 2;
+            op.kind = (uint8_t)(EU_SH_UNION + (int)s.operation);
+            op.param = 0;
+        } else {
+            n_leaves++;
+            op.param = (uint32_t)params.size();
+            switch (s.kind) {
+            case Shape::VoidShape: op.kind = EU_SH_VOID; len = 0; break;
+            case Shape::Sphere:
+                op.kind = EU_SH_SPHERE; len = 2;
+                for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+                params.push_back(s.r); params.push_back(s.r * s.r);
+                break;
+            case Shape::Hyperplane:
+                op.kind = EU_SH_PLANE; len = 1;
+                for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+                params.push_back(s.r);
+                break;
+            case Shape::HalfSpace: {
+                op.kind = EU_SH_HALFSPACE; len = 1;
+                for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+                params.push_back(s.r); params.push_back(s.signum);
+                double k = -s.signum;                                   /* shape.rs:860 normal *= -signum */
+                for (int i = 0; i < D; i++) params.push_back(s.a[i] * k);
+                break;
+            }
+            default:
+                op.kind = EU_SH_CYLINDER; len = 2;
+                for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+                for (int i = 0; i < D; i++) params.push_back(s.b[i]);
+                params.push_back(s.r); params.push_back(s.r * s.r);
+                break;
+            }
+            uint32_t use = base_use + len;
+            if (use > hit_cap) hit_cap = use;
+            if (depth + 1 > list_depth) list_depth = depth + 1;
+        }
+        if (ops.size() >= 65535) fail(ParserError::CustomError, "too many shape nodes");
+        ops.push_back(op);
+        return len;
+    }
+
+    uint64_t emit_expr(const Expr &e, const std::string &legend) {
+        uint32_t off = (uint32_t)code.size();
+        for (auto &t : e.rpn) {
+            uint32_t arg = t.arg;
+            if (t.op == EU_RPN_VAR) {
+                /* material.rs:76-89: one legend character per component; an unknown variable would
+                 * panic at the first evaluation ("Could not evaluate the expression.") */
+                int idx = -1;
+                if (t.var.size() == 1) for (int i = 0; i < D && i < (int)legend.size(); i++) if (legend[(size_t)i] == t.var[0]) idx = i;
+                if (idx < 0) fail(ParserError::CustomError, "Could not evaluate the expression. (unknown variable `" + t.var + "`)");
+                arg = (uint32_t)idx;
+            }
+            code.push_back((uint64_t)t.op | ((uint64_t)arg << 32));
+            if (t.op == EU_RPN_CONST) { uint64_t w; memcpy(&w, &t.k, 8); code.push_back(w); }
+        }
+        uint32_t len = (uint32_t)code.size() - off;
+        uint32_t sd = (uint32_t)e.stack_depth();
+        if (sd > rpn_depth) rpn_depth = sd;
+        return (uint64_t)off | ((uint64_t)len << 32);
+    }
+
+    uint32_t material_id(const MaterialPtr &m) {
+        auto it = mat_ids.find(m.get());
+        if (it != mat_ids.end()) return it->second;
+        if (m->dim != D) fail(ParserError::CustomError, "material dimension does not match the universe");
+        EuFlatMaterial fm{};
+        if (m->kind == Material::LinearSpace) {
+            if ((int)m->legend.size() < D) fail(ParserError::CustomError, "The legend is too short! Make sure it is sufficient for " + std::to_string(D) + " dimensions.");
+            fm.first_transform = (uint32_t)(transforms.size() / 8);
+            for (auto &tr : m->transformations) {
+                if ((int)tr->expressions.size() != D)
+                    fail(ParserError::CustomError, "The number of functions must be equal to the number of dimensions (" + std::to_string(D) + ")!");
+                uint64_t rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < D; i++) { rec[i] = emit_expr(tr->expressions[(size_t)i].expression, m->legend); rec[4 + i] = emit_expr(tr->expressions[(size_t)i].inverse_expression, m->legend); }
+                transforms.insert(transforms.end(), rec, rec + 8);
+            }
+            fm.kind = EU_MAT_LINEAR | ((uint32_t)m->transformations.size() << 8);
+        } else fm.kind = EU_MAT_VACUUM;
+        uint32_t id = (uint32_t)materials.size();
+        materials.push_back(fm);
+        mat_ids[m.get()] = id;
+        return id;
+    }
+
+    uint32_t mapped_id(const std::shared_ptr<MappedTexture> &m) {
+        auto it = mapped_ids.find(m.get());
+        if (it != mapped_ids.end()) return it->second;
+        EuFlatMapped fm{};
+        fm.tex_kind = m->texture->kind; fm.uv_kind = 0;
+        fm.w = m->texture->w; fm.h = m->texture->h; fm.texels = 0;
+        for (int i = 0; i < 3; i++) fm.center[i] = m->uvfn->center[i];
+        fm.wd = (double)fm.w; fm.hd = (double)fm.h;
+        uint32_t id = (uint32_t)mapped.size();
+        mapped.push_back(fm); textures.push_back(m->texture);
+        mapped_ids[m.get()] = id;
+        return id;
+    }
+
+    static void perlin_perm(uint32_t seed, uint8_t *perm512) {
+        uint8_t p[256];
+        for (int i = 0; i < 256; i++) p[i] = (uint8_t)i;
+        uint32_t st = seed + 0x9E3779B9u;
+        if (st == 0) st = 1;
+        for (int i = 255; i >= 1; i--) {
+            st ^= st << 13; st ^= st >> 17; st ^= st << 5;
+            uint32_t j = st % (uint32_t)(i + 1);
+            uint8_t tmp = p[i]; p[i] = p[j]; p[j] = tmp;
+        }
+        for (int i = 0; i < 512; i++) perm512[i] = p[i & 255];
+    }
+
+    /* post-order colour program; returns stack depth needed */
+    uint32_t emit_color(const SurfaceColor &c) {
+        EuFlatColorOp op{};
+        op.kind = c.kind;
+        uint32_t depth = 1;
+        switch (c.kind) {
+        case EU_COL_BLEND: {
+            uint32_t da = emit_color(*c.source);
+            uint32_t db = emit_color(*c.destination);
+            depth = da > db + 1 ? da : db + 1;
+            op.fn = c.blend->fn; op.v[0] = c.blend->ratio;
+            break;
+        }
+        case EU_COL_UNIFORM: memcpy(op.c0, c.c0, sizeof op.c0); break;
+        case EU_COL_ILLUM_GLOBAL: memcpy(op.c0, c.c0, sizeof op.c0); memcpy(op.c1, c.c1, sizeof op.c1); break;
+        case EU_COL_ILLUM_DIR:
+            memcpy(op.c0, c.c0, sizeof op.c0); memcpy(op.c1, c.c1, sizeof op.c1); memcpy(op.v, c.v, sizeof op.v);
+            for (int i = 0; i < D; i++) op.v[i] = -c.v[i];      /* surface.rs:403 uses -light_direction */
+            break;
+        case EU_COL_PERLIN: {
+            if (D != 3) fail(ParserError::CustomError, "surface_color_perlin_hue is 3-D only");
+            std::array<uint8_t, 512> perm;
+            perlin_perm(c.seed, perm.data());
+            op.aux = (uint32_t)perlin.size();
+            perlin.push_back(perm);
+            op.v[0] = c.v[0]; op.v[1] = c.v[1];
+            break;
+        }
+        default: op.aux = mapped_id(c.mapped); break;
+        }
+        color_ops.push_back(op);
+        return depth;
+    }
+
+    uint32_t surface_id(const std::shared_ptr<ComposableSurface> &s) {
+        auto it = surf_ids.find(s.get());
+        if (it != surf_ids.end()) return it->second;
+        EuFlatSurface fs{};
+        fs.ratio_kind = s->reflection_ratio->kind; fs.ratio_p0 = s->reflection_ratio->p0; fs.ratio_p1 = s->reflection_ratio->p1;
+        fs.thr_kind = s->threshold_direction->kind; fs.thr_p0 = s->threshold_direction->p0;
+        fs.thr_p0_inv = 1.0 / s->threshold_direction->p0;       /* surface.rs:278 */
+        fs.color_first = (uint32_t)color_ops.size();
+        uint32_t depth = emit_color(*s->surface_color);
+        if (depth > color_depth) color_depth = depth;
+        fs.color_root = (uint32_t)color_ops.size() - 1;
+        uint32_t id = (uint32_t)surfaces.size();
+        surfaces.push_back(fs);
+        surf_ids[s.get()] = id;
+        return id;
+    }
+};
+}  // namespace
+
+FlatScene flatten(const Universe &u) {
+    Flattener f;
+    f.D = u.dim;
+    if (u.dim != 3 && u.dim != 4) fail(ParserError::CustomError, "only 3-D and 4-D universes exist");
+    if (!u.background) fail(ParserError::CustomError, "the universe has no background");
+    for (auto &e : u.entities) {
+        EuFlatEntity fe{};
+        uint32_t before_cap = f.hit_cap;
+        f.hit_cap = 0;
+        fe.shape_first = (uint16_t)f.ops.size();
+        f.emit_shape(*e->shape, 0, 0);
+        fe.shape_root = (uint16_t)(f.ops.size() - 1);
+        fe.max_hits = f.hit_cap;
+        if (before_cap > f.hit_cap) f.hit_cap = before_cap;
+        fe.material = (uint16_t)f.material_id(e->material);
+        fe.surface = e->surface ? (int16_t)f.surface_id(e->surface) : (int16_t)-1;
+        f.entities.push_back(fe);
+    }
+    uint32_t bg = f.mapped_id(u.background);
+    if (u.background->dim != u.dim) fail(ParserError::CustomError, "background dimension mismatch");
+
+    FlatScene out;
+    auto &w = out.words;
+    w.resize(EU_FLAT_HEADER_WORDS, 0);
+    EuFlatHeader h{};
+    h.magic = EU_FLAT_MAGIC; h.version = EU_FLAT_VERSION; h.dim = (uint32_t)u.dim;
+    auto append = [&](const void *data, size_t bytes) -> uint32_t {
+        uint32_t off = (uint32_t)w.size();
+        size_t nw = (bytes + 7) / 8;
+        w.resize(w.size() + nw, 0);
+        if (bytes) memcpy(&w[off], data, bytes);
+        return off;
+    };
+    h.n_ops = (uint32_t)f.ops.size(); h.off_ops = append(f.ops.data(), f.ops.size() * sizeof(EuShapeOp));
+    h.n_params = (uint32_t)f.params.size(); h.off_params = append(f.params.data(), f.params.size() * 8);
+    h.n_entities = (uint32_t)f.entities.size(); h.off_entities = append(f.entities.data(), f.entities.size() * sizeof(EuFlatEntity));
+    h.n_materials = (uint32_t)f.materials.size(); h.off_materials = append(f.materials.data(), f.materials.size() * sizeof(EuFlatMaterial));
+    h.n_transforms = (uint32_t)(f.transforms.size() / 8); h.off_transforms = append(f.transforms.data(), f.transforms.size() * 8);
+    h.n_code = (uint32_t)f.code.size(); h.off_code = append(f.code.data(), f.code.size() * 8);
+    h.n_surfaces = (uint32_t)f.surfaces.size(); h.off_surfaces = append(f.surfaces.data(), f.surfaces.size() * sizeof(EuFlatSurface));
+    h.n_color_ops = (uint32_t)f.color_ops.size(); h.off_color_ops = append(f.color_ops.data(), f.color_ops.size() * sizeof(EuFlatColorOp));
+    h.n_mapped = (uint32_t)f.mapped.size(); h.off_mapped = append(f.mapped.data(), f.mapped.size() * sizeof(EuFlatMapped));
+    h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
+    h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
+    h.n_words = (uint32_t)w.size();
+    memcpy(w.data(), &h, sizeof h);
+    out.textures = f.textures;
+    out.info.dim = u.dim;
+    out.info.n_entities = h.n_entities; out.info.n_shape_ops = h.n_ops; out.info.n_leaves = f.n_leaves;
+    out.info.n_materials = h.n_materials; out.info.n_surfaces = h.n_surfaces; out.info.n_color_ops = h.n_color_ops;
+    out.info.n_textures = h.n_mapped; out.info.hit_cap = h.hit_cap; out.info.list_depth = h.list_depth;
+    out.info.flat_bytes = h.n_words * 8;
+    return out;
+}
+
+}  // namespace euclider

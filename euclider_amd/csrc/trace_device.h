@@ -1,0 +1,814 @@
+/*
+ * trace_device.h -- the per-ray trace loop for gfx950, device side.
+ *
+ * Replaces, for one ray per lane, the reference's
+ *   Universe::trace / trace_closest / intersect / material_at   (src/universe/mod.rs:61-184,229-271)
+ *   the leaf intersectors and the four CSG iterators             (src/universe/entity/shape.rs:188-1038)
+ *   ComposableSurface::get_color and its providers               (src/universe/entity/surface.rs:39-542)
+ *   Vacuum / LinearSpace enter+exit                              (src/universe/entity/material.rs:32-163)
+ *   camera ray generation                                        (src/universe/d3/entity/camera.rs:155-185,
+ *                                                                 src/universe/d4/entity/camera.rs:146-176)
+ * (paths relative to /root/reference).
+ *
+ * How it differs from the reference's shape (it is not a translation):
+ *  - no recursion: a lane runs a small state machine (TRACE one segment / RETURN through pending
+ *    frames); the reflect/transmit recursion lives in an explicit per-lane frame stack;
+ *  - no lazy iterator objects: an entity's CSG tree is a post-order program; every node's hit
+ *    stream is produced eagerly into a per-lane hit stack of compact (t, leaf|hit#|flip) records --
+ *    location and normal are recomputed from the leaf only for the winning hit;
+ *  - the scene is read through wave-uniform addresses from an LDS copy (broadcast reads);
+ *  - the arithmetic (operation order, IEEE semantics, NaN behaviour, mid-recursion u8
+ *    quantisation) is kept exactly, so results are bit-identical to the CPU restatement.
+ */
+#ifndef EU_TRACE_DEVICE_H
+#define EU_TRACE_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eu_math.h"
+#include "flat_scene.h"
+
+#define EU_DEV __device__ __forceinline__
+#define EU_MAX_DEPTH 16
+#define EU_PI_C 3.14159265358979323846264338327950288
+#define EU_FRAC_PI_2_C 1.57079632679489661923132169163975144
+#define EU_EPS 1.0e-6 /* nalgebra 0.8.2 approx_epsilon (UNVERIFIED), surface.rs:84,133 */
+
+struct EuDevCamera {
+    double location[4], forward[4], up[4], right[4];
+    double dist;            /* sqrt(w*w+h*h) / (2 tan(fov/2)), camera.rs:176-179 */
+    uint32_t max_depth, pad;
+};
+
+struct EuDevFrame {
+    uint32_t width, height, row_begin, row_end;
+    uint32_t tiles_x, n_tiles, debug_crosshair, single_pixel;
+    uint32_t single_x, single_y;
+    double time_s;          /* time_millis, d3/entity/surface.rs:32 */
+};
+
+struct EuDevCounters {      /* device memory, zeroed before each launch */
+    unsigned long long next_item;
+    unsigned long long rays, bg_samples, nan_pixels, errors;
+};
+
+/* ------------------------------------------------------------------ scene view */
+struct EuScene {
+    const uint64_t *w;      /* blob (LDS or global) */
+    uint32_t off_ops, off_params, off_entities, n_entities, off_materials, off_transforms, off_code;
+    uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background;
+
+    EU_DEV void init(const uint64_t *base) {
+        w = base;
+        const EuFlatHeader *h = (const EuFlatHeader *)base;
+        off_ops = h->off_ops; off_params = h->off_params; off_entities = h->off_entities; n_entities = h->n_entities;
+        off_materials = h->off_materials; off_transforms = h->off_transforms; off_code = h->off_code;
+        off_surfaces = h->off_surfaces; off_color_ops = h->off_color_ops; off_mapped = h->off_mapped;
+        off_perlin = h->off_perlin; background = h->background;
+    }
+    EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
+    EU_DEV double dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
+    EU_DEV void op(uint32_t i, uint32_t &kind, uint32_t &first, uint32_t &param) const {
+        uint64_t x = w[off_ops + i];
+        kind = (uint32_t)(x & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
+    }
+    EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params + off); }
+    EU_DEV const EuFlatEntity *entity(uint32_t e) const { return (const EuFlatEntity *)(w + off_entities + 2 * e); }
+    EU_DEV const EuFlatSurface *surface(uint32_t s) const { return (const EuFlatSurface *)(w + off_surfaces + 8 * s); }
+    EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
+    EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
+    EU_DEV const uint8_t *perlin(uint32_t p) const { return (const uint8_t *)(w + off_perlin + 64 * p); }
+};
+
+/* ------------------------------------------------------------------ vectors (x -> w summation order) */
+template <int D> EU_DEV double vdot(const double *a, const double *b) {
+    double s = a[0] * b[0];
+#pragma unroll
+    for (int i = 1; i < D; i++) s = s + a[i] * b[i];
+    return s;
+}
+template <int D> EU_DEV double vnsq(const double *a) { return vdot<D>(a, a); }
+template <int D> EU_DEV double vnorm(const double *a) { return sqrt(vnsq<D>(a)); }
+template <int D> EU_DEV void vnormalize(const double *a, double *o) {
+    double n = vnorm<D>(a);
+#pragma unroll
+    for (int i = 0; i < D; i++) o[i] = a[i] / n;
+}
+template <int D> EU_DEV double angle_between(const double *a, const double *b) {   /* util.rs:712-722 */
+    double r = eu_acos(vdot<D>(a, b) / (vnorm<D>(a) * vnorm<D>(b)));
+    return (r != r) ? 0.0 : r;
+}
+EU_DEV double rust_signum(double x) { if (x != x) return x; return (eu_hi(x) >> 31) ? -1.0 : 1.0; }
+EU_DEV double rust_min(double a, double b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
+EU_DEV double rust_max(double a, double b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
+EU_DEV double clamp01(double v) { if (v < 0.0) return 0.0; if (v > 1.0) return 1.0; return v; }
+EU_DEV bool is_normal_f64(double x) { uint32_t e = (eu_hi(x) >> 20) & 0x7ff; return e != 0 && e != 0x7ff; }
+EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
+    double rem = fmod(a, b);
+    if (rem == 0.0) return 0.0;
+    if (a < 0.0) return b + rem;
+    return rem;
+}
+
+/* ------------------------------------------------------------------ leaves */
+/* sphere (shape.rs:667-693) and cylinder (shape.rs:962-988) share the root selection */
+EU_DEV int quad_roots(double a, double b, double c, double &t_first, double &t_second) {
+    double d = b * b - 4.0 * a * c;
+    if (d < 0.0) return 0;
+    double d_sqrt = sqrt(d);
+    double t1 = (-b - d_sqrt) / (2.0 * a);
+    double t2 = (-b + d_sqrt) / (2.0 * a);
+    if (t1 >= 0.0) {
+        t_first = t1;
+        if (t2 >= 0.0) { t_second = t2; return 2; }
+        return 1;
+    } else if (t2 >= 0.0) { t_first = t2; return 1; }
+    return 0;
+}
+
+template <int D> EU_DEV int leaf_hits(uint32_t kind, const double *P, const double *o, const double *d, double &t0, double &t1) {
+    switch (kind) {
+    case EU_SH_SPHERE: {                                  /* shape.rs:652-731 */
+        double rel[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) rel[i] = o[i] - P[i];
+        double a = vnsq<D>(d);
+        double b = 2.0 * vdot<D>(d, rel);
+        double c = vnsq<D>(rel) - P[D + 1];
+        return quad_roots(a, b, c, t0, t1);
+    }
+    case EU_SH_PLANE: case EU_SH_HALFSPACE: {             /* shape.rs:779-809, 843-870 */
+        double t = -(vdot<D>(P, o) + P[D]) / vdot<D>(P, d);
+        if (t < 0.0) return 0;
+        t0 = t;
+        return 1;
+    }
+    case EU_SH_CYLINDER: {                                /* shape.rs:935-1027 */
+        const double *ax = P + D;
+        double a_vec[D], delta[D], c_vec[D];
+        double k = vdot<D>(d, ax);
+#pragma unroll
+        for (int i = 0; i < D; i++) a_vec[i] = d[i] - ax[i] * k;
+#pragma unroll
+        for (int i = 0; i < D; i++) delta[i] = o[i] - P[i];
+        double k2 = vdot<D>(delta, ax);
+#pragma unroll
+        for (int i = 0; i < D; i++) c_vec[i] = delta[i] - ax[i] * k2;
+        double a = vnsq<D>(a_vec);
+        double b = (1.0 + 1.0) * vdot<D>(a_vec, c_vec);
+        double c = vnsq<D>(c_vec) - P[2 * D + 1];
+        return quad_roots(a, b, c, t0, t1);
+    }
+    default: return 0;                                    /* VoidShape, shape.rs:622-631 */
+    }
+}
+
+template <int D> EU_DEV void cyl_axis_point(const double *P, const double *to, double *out) {   /* shape.rs:929-932 */
+    const double *ax = P + D;
+    double dl[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) dl[i] = to[i] - P[i];
+    double k = vdot<D>(ax, dl);
+#pragma unroll
+    for (int i = 0; i < D; i++) out[i] = P[i] + ax[i] * k;
+}
+
+template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const double *p) {
+    switch (kind) {
+    case EU_SH_VOID: return true;                         /* shape.rs:616-618 */
+    case EU_SH_SPHERE: {                                  /* shape.rs:735-737 */
+        double dl[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) dl[i] = P[i] - p[i];
+        return vnsq<D>(dl) <= P[D + 1];
+    }
+    case EU_SH_HALFSPACE: {                               /* shape.rs:874-880 */
+        double result = vdot<D>(P, p) + P[D];
+        return P[D + 1] == rust_signum(result);
+    }
+    case EU_SH_CYLINDER: {                                /* shape.rs:1032-1037 */
+        double q[D], v[D];
+        cyl_axis_point<D>(P, p, q);
+#pragma unroll
+        for (int i = 0; i < D; i++) v[i] = p[i] - q[i];
+        return vnsq<D>(v) <= P[2 * D + 1];
+    }
+    default: return false;                                /* Hyperplane, shape.rs:814-816 */
+    }
+}
+
+/* is_point_inside of the subtree ops[first..root] (shape.rs:589-600), evaluated without
+ * short-circuit on a bit stack (the leaf tests are pure, so the result is the same) */
+template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, uint32_t root, const double *p) {
+    uint64_t st = 0;
+    for (uint32_t i = first; i <= root; i++) {
+        uint32_t kind, f, param;
+        S.op(i, kind, f, param);
+        if (kind < EU_SH_UNION) {
+            st = (st << 1) | (leaf_inside<D>(kind, S.params(param), p) ? 1ull : 0ull);
+        } else {
+            uint64_t b = st & 1, a = (st >> 1) & 1;
+            st >>= 2;
+            uint64_t r = (kind == EU_SH_UNION) ? (a | b) : (kind == EU_SH_INTERSECTION) ? (a & b)
+                       : (kind == EU_SH_COMPLEMENT) ? (a & (b ^ 1)) : (a ^ b);
+            st = (st << 1) | r;
+        }
+    }
+    return (st & 1) != 0;
+}
+
+/* ------------------------------------------------------------------ per-lane state */
+/* hit code: bits 0..23 op index of the leaf, bit 30 = second root of the leaf, bit 31 = normal flipped */
+#define EU_HIT_SECOND 0x40000000u
+#define EU_HIT_FLIP 0x80000000u
+
+template <int D, int CAP> struct HitStack {
+    double t[CAP];
+    uint32_t c[CAP];
+};
+
+enum { FR_OVER = 0, FR_TRANS_THEN_REFL = 1, FR_COMBINE = 2 };
+
+template <int D> struct FrameStack {
+    double ratio[EU_MAX_DEPTH];
+    uint32_t meta[EU_MAX_DEPTH];     /* kind | depth_of_second_child << 8 | entity << 16 */
+    uint32_t px[EU_MAX_DEPTH];
+    double data[EU_MAX_DEPTH][2 * D];
+};
+
+struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
+
+struct Rgba { double r, g, b, a; };
+
+/* ------------------------------------------------------------------ CSG: eager post-order evaluation */
+/* Evaluates entity shape program ops[first..root] for ray (o, d).  On return the entity's hit
+ * stream is HS[0 .. n); returns n (only element 0 is used by trace_closest, universe/mod.rs:114). */
+template <int D, int CAP>
+EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
+                           HitStack<D, CAP> &HS, LaneCounters &cnt) {
+    uint32_t sp = 0;          /* entries in use */
+    uint64_t lens = 0;        /* stack of list lengths, 8 bits each (bit 7: stream repeats its last element forever) */
+    for (uint32_t i = first; i <= root; i++) {
+        uint32_t kind, f, param;
+        S.op(i, kind, f, param);
+        if (kind < EU_SH_UNION) {
+            double t0 = 0.0, t1 = 0.0;
+            int n = leaf_hits<D>(kind, S.params(param), o, d, t0, t1);
+            if (sp + 2 > CAP) { cnt.errors++; n = 0; }
+            if (n >= 1) { HS.t[sp] = t0; HS.c[sp] = i; }
+            if (n >= 2) { HS.t[sp + 1] = t1; HS.c[sp + 1] = i | EU_HIT_SECOND; }
+            sp += (uint32_t)n;
+            lens = (lens << 8) | (uint64_t)n;
+            continue;
+        }
+        /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
+        uint32_t kb, fb, pb;
+        S.op(i - 1, kb, fb, pb);
+        const uint32_t ra = fb - 1, fa = f, rb = i - 1;
+        const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
+        lens >>= 16;
+        const uint32_t nb = lb & 0x7f, na = la & 0x7f;
+        const bool rep_a = (la & 0x80) != 0 && na > 0, rep_b = (lb & 0x80) != 0 && nb > 0;
+        const uint32_t b0 = sp - nb, a0 = b0 - na, o0 = sp;
+        uint32_t ia = 0, ib = 0, no = 0;
+        bool out_rep = false;
+        const uint32_t guard_max = 4 * (na + nb) + 8;
+        for (uint32_t guard = 0;; guard++) {
+            const bool sa = ia < na || rep_a, sb = ib < nb || rep_b;
+            if (!sa && !sb) break;
+            if (guard >= guard_max || o0 + no >= CAP) { cnt.errors++; break; }   /* runaway (reference would spin) / capacity */
+            double ta = 0.0, tb = 0.0; uint32_t ca = 0, cb = 0;
+            if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = HS.t[k]; ca = HS.c[k]; }
+            if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = HS.t[k]; cb = HS.c[k]; }
+            const bool both = sa && sb;
+            const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
+            if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
+                HS.t[o0 + no] = ta; HS.c[o0 + no] = ca; no++;
+                out_rep = true;
+                break;
+            }
+            /* consuming the repeated tail of a never-ending child stream leaves the iterator state
+             * unchanged: the same decision recurs forever */
+            const bool stuck = take_a ? (ia >= na) : (ib >= nb);
+            const double t = take_a ? ta : tb;
+            uint32_t c = take_a ? ca : cb;
+            double loc[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) loc[k] = o[k] + d[k] * t;
+            const bool ins = take_a ? inside_subtree<D>(S, fb, rb, loc) : inside_subtree<D>(S, fa, ra, loc);
+            if (take_a) ia++; else ib++;
+            bool emit = false, end = false;
+            switch (kind) {
+            case EU_SH_UNION:                                /* shape.rs:212-264 */
+                if (both) emit = !ins; else { if (ins) end = true; else emit = true; }
+                break;
+            case EU_SH_INTERSECTION:                         /* shape.rs:291-340 */
+                if (both) emit = ins; else { if (ins) emit = true; else end = true; }
+                break;
+            case EU_SH_COMPLEMENT:                           /* shape.rs:365-409 */
+                if (take_a) emit = !ins;                      /* only reachable with both present */
+                else { if (ins) { emit = true; c ^= EU_HIT_FLIP; } else if (!both) end = true; }
+                break;
+            default:                                         /* SymmetricDifference, shape.rs:436-496 */
+                emit = true;
+                if (ins) c ^= EU_HIT_FLIP;
+                break;
+            }
+            if (emit) { HS.t[o0 + no] = t; HS.c[o0 + no] = c; no++; }
+            if (end) break;
+            if (stuck) { if (emit) out_rep = true; else cnt.errors++; break; }   /* no output forever: the reference would spin */
+        }
+        for (uint32_t k = 0; k < no; k++) { HS.t[a0 + k] = HS.t[o0 + k]; HS.c[a0 + k] = HS.c[o0 + k]; }
+        sp = a0 + no;
+        lens = (lens << 8) | (uint64_t)(no | (out_rep ? 0x80u : 0u));
+    }
+    return (uint32_t)(lens & 0x7f);
+}
+
+/* normal of the hit described by `code` at parameter t (recomputed from the leaf) */
+template <int D>
+EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const double *d, const double *loc, double *n) {
+    uint32_t kind, f, param;
+    S.op(code & 0xffffffu, kind, f, param);
+    const double *P = S.params(param);
+    switch (kind) {
+    case EU_SH_SPHERE: {                                  /* shape.rs:708-709 */
+        double v[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) v[i] = loc[i] - P[i];
+        vnormalize<D>(v, n);
+        break;
+    }
+    case EU_SH_PLANE:
+#pragma unroll
+        for (int i = 0; i < D; i++) n[i] = P[i];
+        break;
+    case EU_SH_HALFSPACE:                                 /* shape.rs:860 */
+#pragma unroll
+        for (int i = 0; i < D; i++) n[i] = P[D + 2 + i];
+        break;
+    default: {                                            /* cylinder: axis point of hit 1 serves both hits (shape.rs:999,1017) */
+        double t0 = 0.0, t1 = 0.0;
+        leaf_hits<D>(kind, P, o, d, t0, t1);
+        double l1[D], q[D], v[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) l1[i] = o[i] + d[i] * t0;
+        cyl_axis_point<D>(P, l1, q);
+#pragma unroll
+        for (int i = 0; i < D; i++) v[i] = loc[i] - q[i];
+        vnormalize<D>(v, n);
+        break;
+    }
+    }
+    if (code & EU_HIT_FLIP) {
+#pragma unroll
+        for (int i = 0; i < D; i++) n[i] = -n[i];
+    }
+}
+
+/* Universe::material_at (universe/mod.rs:229-251): first entity containing the point */
+template <int D> EU_DEV int material_at(const EuScene &S, const double *p) {
+    for (uint32_t e = 0; e < S.n_entities; e++) {
+        const EuFlatEntity *E = S.entity(e);
+        if (inside_subtree<D>(S, E->shape_first, E->shape_root, p)) return (int)e;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ materials */
+EU_DEV double pow_int(double x, double y) {   /* meval powf restricted to integral |y| <= 64 (documented deviation) */
+    if (!(y == floor(y)) || fabs(y) > 64.0) return __longlong_as_double(0x7ff8000000000000ll);
+    int n = (int)fabs(y);
+    double r = 1.0;
+    for (int i = 0; i < n; i++) r = r * x;
+    return (y < 0.0) ? 1.0 / r : r;
+}
+
+template <int D> EU_DEV double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
+    uint32_t off = (uint32_t)prog, len = (uint32_t)(prog >> 32);
+    double st[8];
+    int sp = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint64_t wd = S.word(S.off_code + off + i);
+        uint32_t op = (uint32_t)wd, arg = (uint32_t)(wd >> 32);
+        switch (op) {
+        case EU_RPN_CONST: i++; st[sp++ & 7] = S.dbl(S.off_code + off + i); break;
+        case EU_RPN_VAR: { double v = ctx[0];
+#pragma unroll
+            for (int k = 1; k < D; k++) if ((int)arg == k) v = ctx[k];
+            st[sp++ & 7] = v; break; }
+        case EU_RPN_NEG: st[(sp - 1) & 7] = -st[(sp - 1) & 7]; break;
+        case EU_RPN_FN: {
+            double y = st[(sp - 1) & 7], x = y;
+            if (arg == EU_FN_MIN || arg == EU_FN_MAX || arg == EU_FN_ATAN2) { sp--; x = st[(sp - 1) & 7]; }
+            double r;
+            switch (arg) {
+            case EU_FN_SQRT: r = sqrt(x); break;
+            case EU_FN_ABS: r = fabs(x); break;
+            case EU_FN_FLOOR: r = floor(x); break;
+            case EU_FN_CEIL: r = ceil(x); break;
+            case EU_FN_MIN: r = rust_min(x, y); break;
+            case EU_FN_MAX: r = rust_max(x, y); break;
+            case EU_FN_SIN: r = eu_sin(x); break;
+            case EU_FN_COS: r = eu_cos(x); break;
+            case EU_FN_TAN: r = eu_tan(x); break;
+            case EU_FN_ASIN: r = eu_asin(x); break;
+            case EU_FN_ACOS: r = eu_acos(x); break;
+            case EU_FN_ATAN: r = eu_atan(x); break;
+            case EU_FN_ATAN2: r = eu_atan2(x, y); break;
+            default: r = rust_signum(x); break;
+            }
+            st[(sp - 1) & 7] = r;
+            break;
+        }
+        default: {
+            double y = st[(sp - 1) & 7]; sp--;
+            double x = st[(sp - 1) & 7];
+            double r;
+            switch (op) {
+            case EU_RPN_ADD: r = x + y; break;
+            case EU_RPN_SUB: r = x - y; break;
+            case EU_RPN_MUL: r = x * y; break;
+            case EU_RPN_DIV: r = x / y; break;
+            case EU_RPN_REM: r = fmod(x, y); break;
+            default: r = pow_int(x, y); break;
+            }
+            st[(sp - 1) & 7] = r;
+            break;
+        }
+        }
+    }
+    return st[0];
+}
+
+/* Material::enter / exit (material.rs:135-162); the evaluation context is the vector BEFORE the
+ * transformation (material.rs:99-111) */
+template <int D> EU_DEV void material_apply(const EuScene &S, uint32_t material, double *dir, bool exit_) {
+    uint64_t m = S.word(S.off_materials + material);
+    uint32_t kind = (uint32_t)m & 0xff, ntr = ((uint32_t)m >> 8), first = (uint32_t)(m >> 32);
+    if (kind != EU_MAT_LINEAR) return;
+    for (uint32_t k = 0; k < ntr; k++) {
+        uint32_t tr = exit_ ? (first + ntr - 1 - k) : (first + k);
+        double ctx[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) ctx[i] = dir[i];
+#pragma unroll
+        for (int i = 0; i < D; i++) dir[i] = eval_rpn<D>(S, S.word(S.off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i), ctx);
+    }
+}
+
+/* ------------------------------------------------------------------ palette 0.2.1 (UNVERIFIED third-party semantics) */
+EU_DEV Rgba into_premultiplied(Rgba c) { double a = clamp01(c.a); return Rgba{c.r * a, c.g * a, c.b * a, a}; }
+EU_DEV Rgba from_premultiplied(Rgba p) {
+    double a = clamp01(p.a);
+    Rgba c;
+    if (is_normal_f64(a)) { c.r = p.r / a; c.g = p.g / a; c.b = p.b / a; }
+    else { c.r = 0.0; c.g = 0.0; c.b = 0.0; }
+    c.a = a;
+    return c;
+}
+EU_DEV double blend_chan(uint32_t fn, double a, double b, double sa, double da) {
+    const double one = 1.0, two = 2.0;
+    switch (fn) {
+    case EU_BL_OVER: return a + b * (one - sa);
+    case EU_BL_INSIDE: return a * da;
+    case EU_BL_OUTSIDE: return a * (one - da);
+    case EU_BL_ATOP: return a * da + b * (one - sa);
+    case EU_BL_XOR: return a * (one - da) + b * (one - sa);
+    case EU_BL_PLUS: return a + b;
+    case EU_BL_MULTIPLY: return a * b + a * (one - da) + b * (one - sa);
+    case EU_BL_SCREEN: return a + b - a * b;
+    case EU_BL_OVERLAY:
+        if (b * two <= da) return two * a * b + a * (one - da) + b * (one - sa);
+        return a * (one + da) + b * (one + sa) - two * a * b - sa * da;
+    case EU_BL_DARKEN: return rust_min(a * da, b * sa) + a * (one - da) + b * (one - sa);
+    case EU_BL_LIGHTEN: return rust_max(a * da, b * sa) + a * (one - da) + b * (one - sa);
+    case EU_BL_DODGE:
+        if (a == sa && !is_normal_f64(b)) return a * (one - da);
+        if (a == sa) return sa * da + a * (one - da) + b * (one - sa);
+        return sa * da * rust_min(one, (b / da) * sa / (sa - a)) + a * (one - da) + b * (one - sa);
+    case EU_BL_BURN:
+        if (!is_normal_f64(a) && b == da) return sa * da + b * (one - sa);
+        if (!is_normal_f64(a)) return b * (one - sa);
+        return sa * da * (one - rust_min(one, (one - b / da) * sa / a)) + a * (one - da) + b * (one - sa);
+    case EU_BL_HARD_LIGHT:
+        if (a * two <= sa) return two * a * b + a * (one - da) + b * (one - sa);
+        return a * (one + da) + b * (one + sa) - two * a * b - sa * da;
+    case EU_BL_SOFT_LIGHT: {
+        double m = is_normal_f64(da) ? b / da : 0.0;
+        if (a * two <= sa) return b * (sa + (two * a - sa) * (one - m)) + a * (one - da) + b * (one - sa);
+        if (b * 4.0 <= da) {
+            double m2 = m * m, m3 = m2 * m;
+            return da * (two * a - sa) * (m3 * 16.0 - m2 * 12.0 - m * 3.0) + a - a * da + b;
+        }
+        return da * (two * a - sa) * (sqrt(m) - m) + a - a * da + b;
+    }
+    case EU_BL_DIFFERENCE: return a + b - two * rust_min(a * da, b * sa);
+    default: return a + b - two * a * b;
+    }
+}
+EU_DEV double blend_alpha(uint32_t fn, double sa, double da) {
+    switch (fn) {
+    case EU_BL_INSIDE: return clamp01(sa * da);
+    case EU_BL_OUTSIDE: return clamp01(sa * (1.0 - da));
+    case EU_BL_ATOP: return clamp01(da);
+    case EU_BL_XOR: return clamp01(sa + da - 2.0 * sa * da);
+    case EU_BL_PLUS: return clamp01(sa + da);
+    default: return clamp01(sa + da - sa * da);
+    }
+}
+EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
+    Rgba o;
+    o.r = blend_chan(fn, s.r, d.r, s.a, d.a);
+    o.g = blend_chan(fn, s.g, d.g, s.a, d.a);
+    o.b = blend_chan(fn, s.b, d.b, s.a, d.a);
+    o.a = blend_alpha(fn, s.a, d.a);
+    return o;
+}
+EU_DEV Rgba blend_rgba(uint32_t fn, Rgba s, Rgba d) { return from_premultiplied(blend_pre(fn, into_premultiplied(s), into_premultiplied(d))); }   /* surface.rs:315-322 */
+EU_DEV Rgba combine_palette_color(Rgba a, Rgba b, double r) {   /* util.rs:265-285 */
+    if (r <= 0.0) return b;
+    if (r >= 1.0) return a;
+    return Rgba{a.r * r + b.r * (1.0 - r), a.g * r + b.g * (1.0 - r), a.b * r + b.b * (1.0 - r), a.a * r + b.a * (1.0 - r)};
+}
+EU_DEV uint32_t to_u8(double c, LaneCounters &cnt) {
+    double v = clamp01(c) * 255.0;
+    if (v != v) { cnt.nan_px++; return 0; }
+    return (uint32_t)v;
+}
+EU_DEV uint32_t to_pixel4(Rgba c, LaneCounters &cnt) {
+    return to_u8(c.r, cnt) | (to_u8(c.g, cnt) << 8) | (to_u8(c.b, cnt) << 16) | (to_u8(c.a, cnt) << 24);
+}
+EU_DEV Rgba new_u8(uint32_t px) {
+    return Rgba{(double)(px & 0xff) / 255.0, (double)((px >> 8) & 0xff) / 255.0, (double)((px >> 16) & 0xff) / 255.0, (double)(px >> 24) / 255.0};
+}
+EU_DEV void hsv_to_rgb(double hue, double saturation, double value, double &r, double &g, double &b) {
+    double deg = hue;
+    if (fabs(deg) < 1.0e9) {
+        while (deg >= 360.0) deg = deg - 360.0;
+        while (deg < 0.0) deg = deg + 360.0;
+    }
+    double c = value * saturation;
+    double h = deg / 60.0;
+    double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
+    double m = value - c;
+    double red, green, blue;
+    if (h >= 0.0 && h < 1.0) { red = c; green = x; blue = 0.0; }
+    else if (h >= 1.0 && h < 2.0) { red = x; green = c; blue = 0.0; }
+    else if (h >= 2.0 && h < 3.0) { red = 0.0; green = c; blue = x; }
+    else if (h >= 3.0 && h < 4.0) { red = 0.0; green = x; blue = c; }
+    else if (h >= 4.0 && h < 5.0) { red = x; green = 0.0; blue = c; }
+    else { red = c; green = 0.0; blue = x; }
+    r = red + m; g = green + m; b = blue + m;
+}
+
+/* ------------------------------------------------------------------ own 4-D gradient noise (documented substitute
+ * for noise 0.4.1 Perlin + rand::random() seed, d3/entity/surface.rs:22-58) */
+EU_DEV double pfade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+EU_DEV double plerp(double t, double a, double b) { return a + t * (b - a); }
+EU_DEV double pgrad4(int hash, double x, double y, double z, double w) {
+    int h = hash & 31;
+    double a = (h < 24) ? x : y;
+    double b = (h < 16) ? y : z;
+    double c = (h < 8) ? z : w;
+    return ((h & 1) ? -a : a) + ((h & 2) ? -b : b) + ((h & 4) ? -c : c);
+}
+EU_DEV int pcell(double f) { double m = fmod(f, 256.0); return (m == m) ? (((int)m) & 255) : 0; }
+EU_DEV double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
+    double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
+    int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
+    double xf = x - fx, yf = y - fy, zf = z - fz, wf = w - fw;
+    double u = pfade(xf), v = pfade(yf), s = pfade(zf), q = pfade(wf);
+    double lw[2];
+    for (int dw = 0; dw < 2; dw++) {
+        double lz[2];
+        for (int dz = 0; dz < 2; dz++) {
+            double ly[2];
+            for (int dy = 0; dy < 2; dy++) {
+                double n[2];
+                for (int dx = 0; dx < 2; dx++) {
+                    int hsh = perm[perm[perm[perm[xi + dx] + yi + dy] + zi + dz] + wi + dw];
+                    n[dx] = pgrad4(hsh, xf - (double)dx, yf - (double)dy, zf - (double)dz, wf - (double)dw);
+                }
+                ly[dy] = plerp(u, n[0], n[1]);
+            }
+            lz[dz] = plerp(v, ly[0], ly[1]);
+        }
+        lw[dw] = plerp(s, lz[0], lz[1]);
+    }
+    return 0.87 * plerp(q, lw[0], lw[1]);
+}
+
+/* ------------------------------------------------------------------ textures */
+EU_DEV bool cast_u32(double x, uint32_t &out, LaneCounters &cnt) {   /* NumCast: None (panic) when NaN / out of range */
+    if (!(x > -1.0 && x < 4294967296.0)) { cnt.errors++; out = 0; return false; }
+    out = (uint32_t)x;
+    return true;
+}
+
+/* MappedTextureImpl::get_color (surface.rs:528-534) = texture(uv_sphere(point)) */
+EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point, LaneCounters &cnt) {
+    const EuFlatMapped *M = S.mapped(id);
+    double p[3], pn[3];                                        /* d3/entity/surface.rs:60-68 (uv_derank drops w) */
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = point[i] - M->center[i];
+    vnormalize<3>(p, pn);
+    double pu = 0.5 + eu_atan2(pn[1], pn[0]) / (2.0 * EU_PI_C);
+    double pv = 0.5 - eu_asin(pn[2]) / EU_PI_C;
+    const uint32_t W = M->w, H = M->h;
+    const uint32_t *tex = (const uint32_t *)M->texels;
+    if (M->tex_kind == EU_TEX_NEAREST) {                       /* surface.rs:434-451 */
+        double x = floor(pu * M->wd), y = floor(pv * M->hd);
+        uint32_t xi, yi;
+        cast_u32(x, xi, cnt); cast_u32(y, yi, cnt);
+        xi = xi % W; yi = yi % H;
+        return new_u8(tex[(size_t)yi * W + xi]);
+    }
+    double x = pu * M->wd - 0.5, y = pv * M->hd - 0.5;        /* surface.rs:453-489 */
+    double ox = x - floor(x), oy = y - floor(y);
+    uint32_t x0, x1, y0, y1;
+    /* the reference casts x and y once per texel (4 texels, surface.rs:462-472); each coordinate
+     * serves two texels, so a failed cast counts twice */
+    if (!cast_u32(remainder_f(x + 0.0, M->wd), x0, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(x + 1.0, M->wd), x1, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(y + 0.0, M->hd), y0, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(y + 1.0, M->hd), y1, cnt)) cnt.errors++;
+    if (x0 >= W) { cnt.errors++; x0 = W - 1; }
+    if (x1 >= W) { cnt.errors++; x1 = W - 1; }
+    if (y0 >= H) { cnt.errors++; y0 = H - 1; }
+    if (y1 >= H) { cnt.errors++; y1 = H - 1; }
+    uint32_t p0 = tex[(size_t)y0 * W + x0], p1 = tex[(size_t)y0 * W + x1];
+    uint32_t p2 = tex[(size_t)y1 * W + x0], p3 = tex[(size_t)y1 * W + x1];
+    double ch[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double c0 = (double)((p0 >> (8 * k)) & 0xff), c1 = (double)((p1 >> (8 * k)) & 0xff);
+        double c2 = (double)((p2 >> (8 * k)) & 0xff), c3 = (double)((p3 >> (8 * k)) & 0xff);
+        ch[k] = ((c0 * (1.0 - ox) + c1 * ox) * (1.0 - oy) + (c2 * (1.0 - ox) + c3 * ox) * oy) / 255.0;
+    }
+    return Rgba{ch[0], ch[1], ch[2], ch[3]};
+}
+
+/* ------------------------------------------------------------------ surface providers */
+template <int D> struct HitCtx {      /* TracingContext, shape.rs:111-125 */
+    double loc[D], dir[D], normal[D], nc[D];
+    bool exiting;
+};
+
+template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, const HitCtx<D> &c) {
+    if (F->ratio_kind == EU_RATIO_UNIFORM) return c.exiting ? 0.0 : F->ratio_p0;     /* surface.rs:200-211 */
+    double normal[D];                                                                 /* surface.rs:213-244 */
+#pragma unroll
+    for (int i = 0; i < D; i++) normal[i] = -c.nc[i];
+    double from_theta = angle_between<D>(c.dir, normal);
+    double from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
+    double to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
+    double to_theta = eu_asin((from_index / to_index) * eu_sin(from_theta));
+    if (to_theta != to_theta) return 1.0;
+    double p1s = from_index * eu_cos(from_theta);
+    double p2s = to_index * eu_cos(to_theta);
+    double p1p = from_index * eu_cos(to_theta);
+    double p2p = to_index * eu_cos(from_theta);
+    double rs = (p1s - p2s) / (p1s + p2s); rs = rs * rs;
+    double rp = (p1p - p2p) / (p1p + p2p); rp = rp * rp;
+    return (rs + rp) / (1.0 + 1.0);
+}
+
+/* GeneralRotation::general_rotation for one vector (util.rs:631-666) */
+template <int D> EU_DEV void general_rotation(const double *self, const double *other, double angle, double *vec) {
+    double orig[D][D], res[D][D];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) orig[r][c] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < D; r++) { orig[r][0] = self[r]; orig[r][1] = other[r]; }
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) res[r][c] = orig[r][c];
+#pragma unroll
+    for (int i = 1; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            double oc[D], rj[D];
+#pragma unroll
+            for (int r = 0; r < D; r++) { oc[r] = orig[r][i]; rj[r] = res[r][j]; }
+            double dd = vdot<D>(rj, oc);
+#pragma unroll
+            for (int r = 0; r < D; r++) orig[r][i] = oc[r] - rj[r] * dd;
+        }
+        double col[D], ncol[D];
+#pragma unroll
+        for (int r = 0; r < D; r++) col[r] = orig[r][i];
+        vnormalize<D>(col, ncol);
+#pragma unroll
+        for (int r = 0; r < D; r++) res[r][i] = ncol[r];
+    }
+    double rot[D][D];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? 1.0 : 0.0;
+    double ca = eu_cos(angle), sa = eu_sin(angle);
+    rot[0][0] = ca; rot[0][1] = -sa; rot[1][0] = sa; rot[1][1] = ca;
+    double tmp[D][D], fin[D][D];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) acc = acc + rot[r][k] * res[c][k];
+            tmp[r][c] = acc;
+        }
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) acc = acc + res[r][k] * tmp[k][c];
+            fin[r][c] = acc;
+        }
+    double out[D];
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; k++) acc = acc + fin[r][k] * vec[k];
+        out[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < D; r++) vec[r] = out[r];
+}
+
+template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, const HitCtx<D> &c, double *out) {
+#pragma unroll
+    for (int i = 0; i < D; i++) out[i] = c.dir[i];
+    if (F->thr_kind == EU_THR_IDENTITY) return;                     /* surface.rs:258-266 */
+    double normal[D];                                               /* surface.rs:268-288 */
+#pragma unroll
+    for (int i = 0; i < D; i++) normal[i] = -c.nc[i];
+    double from_theta = angle_between<D>(c.dir, normal);
+    double modifier = c.exiting ? F->thr_p0 : F->thr_p0_inv;
+    double to_theta = eu_asin(modifier * eu_sin(from_theta));
+    double angle_delta = to_theta - from_theta;
+    general_rotation<D>(normal, c.dir, angle_delta, out);
+}
+
+/* the surface-colour provider tree, evaluated as a post-order program on a small stack */
+template <int D>
+EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, const HitCtx<D> &c, double time_s, LaneCounters &cnt) {
+    Rgba st[4];
+    int sp = 0;
+    for (uint32_t i = F->color_first; i <= F->color_root; i++) {
+        const EuFlatColorOp *C = S.color_op(i);
+        Rgba v;
+        switch (C->kind) {
+        case EU_COL_UNIFORM: v = Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}; break;       /* surface.rs:424-429 */
+        case EU_COL_BLEND: {                                                                  /* surface.rs:295-322 */
+            Rgba dst = st[(sp - 1) & 3], src = st[(sp - 2) & 3];
+            sp -= 2;
+            v = (C->fn == EU_BL_RATIO) ? combine_palette_color(src, dst, C->v[0]) : blend_rgba(C->fn, src, dst);
+            break;
+        }
+        case EU_COL_ILLUM_GLOBAL: {                                                           /* surface.rs:410-422 */
+            double original_angle = angle_between<D>(c.nc, c.dir);
+            double angle = EU_PI_C - original_angle;
+            double ratio = angle / EU_FRAC_PI_2_C;
+            v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
+            break;
+        }
+        case EU_COL_ILLUM_DIR: {                                                              /* surface.rs:392-408 */
+            double normal[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) normal[k] = c.normal[k];
+            if (angle_between<D>(c.dir, normal) > EU_FRAC_PI_2_C) {
+#pragma unroll
+                for (int k = 0; k < D; k++) normal[k] = -normal[k];
+            }
+            double nl[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) nl[k] = C->v[k];            /* = -light_direction, negated at load */
+            double angle = angle_between<D>(normal, nl);
+            double ratio = 1.0 - angle / EU_PI_C;
+            v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
+            break;
+        }
+        case EU_COL_PERLIN: {                                                                 /* d3/entity/surface.rs:22-40 */
+            double value = perlin4(S.perlin(C->aux), c.loc[0] / C->v[0], c.loc[1] / C->v[0], c.loc[D > 2 ? 2 : 0] / C->v[0], time_s * C->v[1]);
+            hsv_to_rgb(value * 360.0, 1.0, 1.0, v.r, v.g, v.b);
+            v.a = 1.0;
+            break;
+        }
+        default: v = mapped_get_color(S, C->aux, c.loc, cnt); break;                          /* surface.rs:536-542 */
+        }
+        st[sp & 3] = v;
+        sp++;
+    }
+    return st[0];
+}
+
+#endif

@@ -1,0 +1,216 @@
+"""Host-side mirror of the reference's loader + `Environment` seam, over the C ABI.
+
+    Parser().parse(json_text)            <-> scene::Parser::default().parse::<Box<Environment>>()
+                                             (/root/reference/src/scene.rs:564,1466-1478)
+    Environment.max_depth()              <-> Environment::max_depth        (universe/mod.rs:290)
+    Environment.trace_screen_point(...)  <-> Environment::trace_screen_point (universe/mod.rs:291-299)
+    Environment.render(dimensions, time, threads, context) -> RawImage2d
+                                         <-> Environment::render           (universe/mod.rs:300-357)
+
+All tracing happens in libeuclider_amd.so on the GPU; this file holds no arithmetic.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from . import textures as _textures
+
+
+class ParserError(Exception):
+    """scene.rs:524-552; `kind` is the variant name."""
+
+    def __init__(self, message):
+        super().__init__(message)
+        self.kind = message.split(":", 1)[0]
+
+
+class EuError(RuntimeError):
+    def __init__(self, code, message=""):
+        super().__init__("euclider_amd error %d %s" % (code, message))
+        self.code = code
+
+
+class SimulationContext:
+    """simulation.rs:167-186 (the fields render() reads)."""
+
+    def __init__(self, resolution=1, debugging=False):
+        self.resolution = resolution
+        self.debugging = debugging
+
+
+class RawImage2d:
+    """glium::texture::RawImage2d<u8> with ClientFormat::U8U8U8 (universe/mod.rs:351-356):
+    `data` is (height, width, 3) uint8, row 0 first (= bottom row on screen)."""
+
+    def __init__(self, data, width, height):
+        self.data, self.width, self.height, self.format = data, width, height, "U8U8U8"
+
+
+def _duration_to_ms(time):
+    """(time * 1000).as_secs() for a duration given in seconds (d3/entity/surface.rs:32)."""
+    return int(float(time) * 1000.0) if not isinstance(time, int) else time * 1000
+
+
+class Environment:
+    def __init__(self, scene_handle, info, camera, substituted_textures):
+        self._scene = scene_handle
+        self.info = info
+        self.camera = camera          # mutable pose (the reference mutates it in Camera::update)
+        self.substituted_textures = substituted_textures
+        self._renderers = {}
+
+    # -- lifetime
+    def close(self):
+        L = _capi.lib()
+        for r in self._renderers.values():
+            L.eu_renderer_destroy(r)
+        self._renderers = {}
+        if self._scene:
+            L.eu_scene_free(self._scene)
+            self._scene = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dim(self):
+        return self.info.dim
+
+    def renderer(self, device=0):
+        if device not in self._renderers:
+            L = _capi.lib()
+            out = C.c_void_p()
+            err = C.create_string_buffer(512)
+            rc = L.eu_renderer_create(self._scene, device, C.byref(out), err, len(err))
+            if rc != _capi.EU_OK:
+                raise EuError(rc, err.value.decode())
+            self._renderers[device] = out
+        return self._renderers[device]
+
+    # -- Environment trait
+    def max_depth(self):
+        return self.camera.max_depth
+
+    def _frame(self, width, height, time_ms, debugging, rows=None):
+        r0, r1 = rows if rows is not None else (0, height)
+        return _capi.Frame(width, height, r0, r1, time_ms, 1 if debugging else 0, 0)
+
+    def trace_screen_point(self, time, max_depth, screen_x, screen_y, screen_width, screen_height, debug=False, device=0):
+        cam = _capi.Camera.from_buffer_copy(self.camera)
+        cam.max_depth = max_depth
+        fr = self._frame(screen_width, screen_height, _duration_to_ms(time), False)
+        rgb = (C.c_double * 3)()
+        rc = _capi.lib().eu_trace_screen_point(self.renderer(device), C.byref(cam), C.byref(fr), screen_x, screen_y, rgb)
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return tuple(rgb)
+
+    def render(self, dimensions, time=0.0, threads=0, context=None, device=0, want_hit_t=False, rows=None):
+        """Environment::render.  `threads` is accepted for signature parity and ignored (the GPU
+        kernel replaces the thread pool).  Returns RawImage2d; `.stats` and `.hit_t` are extras."""
+        context = context or SimulationContext()
+        width, height = dimensions
+        bw, bh = width // context.resolution, height // context.resolution     # universe/mod.rs:308-309
+        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows)
+        nrows = fr.row_end - fr.row_begin
+        rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
+        hit = np.zeros((nrows, bw), dtype=np.float64) if want_hit_t else None
+        st = _capi.Stats()
+        rc = _capi.lib().eu_render(self.renderer(device), C.byref(self.camera), C.byref(fr), rgb.ctypes.data,
+                                   hit.ctypes.data if hit is not None else None, C.byref(st))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        img = RawImage2d(rgb, bw, nrows)
+        img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
+        img.hit_t = hit
+        return img
+
+    def render_device(self, frame, rgba_ptr, hit_t_ptr=None, stream=None, device=0, camera=None):
+        """Asynchronous render into caller-owned DEVICE memory (e.g. a torch tensor's data_ptr())."""
+        cam = camera if camera is not None else self.camera
+        rc = _capi.lib().eu_render_device(self.renderer(device), C.byref(cam), C.byref(frame), stream, rgba_ptr, hit_t_ptr)
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+
+    def stats(self, device=0):
+        st = _capi.Stats()
+        rc = _capi.lib().eu_renderer_stats(self.renderer(device), C.byref(st))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
+
+    def kernel_ms(self, device=0):
+        ms = C.c_float()
+        rc = _capi.lib().eu_renderer_kernel_ms(self.renderer(device), C.byref(ms))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return ms.value
+
+
+class Parser:
+    """scene::Parser (scene.rs:554-1478).  `texture_dirs`: where relative texture paths are resolved
+    (the reference resolves them against the process CWD, scene.rs:1053)."""
+
+    def __init__(self, texture_dirs=None, random_seed=0, texture_overrides=None):
+        self.texture_dirs = list(texture_dirs) if texture_dirs is not None else [os.getcwd()]
+        self.random_seed = random_seed
+        self.texture_overrides = dict(texture_overrides or {})
+
+    @staticmethod
+    def default():
+        return Parser()
+
+    def parse(self, text):
+        L = _capi.lib()
+        keep = []
+
+        def loader(user, path, pw, ph, prgba):
+            try:
+                p = path.decode()
+                img = self.texture_overrides.get(p)
+                if img is None:
+                    img = _textures.load_rgba(p, self.texture_dirs)
+                if img is None:
+                    return 1        # the C++ loader substitutes the procedural grid and counts it
+                img = np.ascontiguousarray(img, dtype=np.uint8)
+                h, w = img.shape[0], img.shape[1]
+                buf = L.eu_alloc(w * h * 4)
+                C.memmove(buf, img.ctypes.data, w * h * 4)
+                pw[0], ph[0] = w, h
+                prgba[0] = buf
+                return 0
+            except Exception:
+                return 2
+
+        cb = _capi.TEXTURE_LOADER(loader)
+        keep.append(cb)
+        opts = _capi.LoadOpts(cb, None, self.random_seed, 0)
+        out = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        rc = L.eu_scene_from_json(data, len(data), C.byref(opts), C.byref(out), err, len(err))
+        if rc == _capi.EU_ERR_PARSE:
+            raise ParserError(err.value.decode())
+        if rc != _capi.EU_OK:
+            raise EuError(rc, err.value.decode())
+        info = _capi.SceneInfo()
+        L.eu_scene_get_info(out, C.byref(info))
+        cam = _capi.Camera()
+        L.eu_scene_default_camera(out, C.byref(cam))
+        return Environment(out, info, cam, 0)
+
+    def parse_file(self, path):
+        with open(path) as f:
+            text = f.read()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(path)))
+        saved = self.texture_dirs
+        self.texture_dirs = saved + [root]
+        try:
+            return self.parse(text)
+        finally:
+            self.texture_dirs = saved

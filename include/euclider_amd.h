@@ -1,0 +1,127 @@
+/*
+ * euclider_amd.h -- C ABI of the MI355X-native trace path (libeuclider_amd.so).
+ *
+ * The reference (Limeth/euclider, pure Rust) has no FFI; the narrowest seam around its hot path
+ * is the `Environment` trait object the window loop holds (/root/reference/src/universe/mod.rs:289-360):
+ *     fn max_depth(&self) -> u32;                                              (:290)
+ *     fn trace_screen_point(&self, time, max_depth, x, y, w, h, debug) -> Rgb<F>;  (:291-299)
+ *     fn render(&self, dimensions, time, threads, context) -> RawImage2d<u8>;   (:300-357)
+ * plus the loader that produces it, `Parser::parse::<Box<Environment>>(&str)`
+ * (/root/reference/src/scene.rs:1466-1478).  A Rust `impl Environment for GpuUniverse` would bind
+ * exactly the functions below (INTEGRATION.md shows the extern "C" block).
+ *
+ * Conventions: every function returns 0 on success or a negative EU_ERR_* code and never throws
+ * or aborts across the boundary; the caller owns all output buffers; scenes are immutable after
+ * construction; a renderer is bound to one HIP device and must not be used from two threads at
+ * once.  There is NO CPU fallback: without a usable HIP device the render entry points fail with
+ * EU_ERR_NO_DEVICE.
+ */
+#ifndef EUCLIDER_AMD_H
+#define EUCLIDER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EU_OK 0
+#define EU_ERR_INVALID_ARGUMENT (-1)
+#define EU_ERR_PARSE (-2)          /* ParserError, scene.rs:524-552; message says which variant */
+#define EU_ERR_NO_DEVICE (-3)
+#define EU_ERR_HIP (-4)
+#define EU_ERR_CAPACITY (-5)       /* scene exceeds a compiled-in kernel capacity */
+#define EU_ERR_TEXTURE (-6)
+
+typedef struct eu_scene eu_scene;        /* a parsed + flattened Universe3 / Universe4 */
+typedef struct eu_renderer eu_renderer;  /* a scene resident in one GPU's HBM + work buffers */
+
+/* Camera pose.  The reference's cameras (d3/entity/camera.rs:31-52, d4/entity/camera.rs:34-58)
+ * only expose `new` / `new_with_location` to the loader; orientation, fov and max_depth are
+ * fixed there (forward +x, up +z, left +y, fov 90, max_depth 10) and mutable only through
+ * interactive input, so the caller passes the pose explicitly. */
+typedef struct {
+    int32_t dim;                 /* 3 or 4, must equal the scene's */
+    uint32_t fov_deg;            /* diagonal field of view in degrees (u8 in the reference) */
+    uint32_t max_depth;          /* Camera::max_depth(), universe/mod.rs:290,310 */
+    uint32_t reserved;
+    double location[4], forward[4], up[4], left[4];
+} eu_camera;
+
+/* One frame = Environment::render's arguments (universe/mod.rs:300-311). */
+typedef struct {
+    uint32_t width, height;      /* buffer dimensions (window / context.resolution) */
+    uint32_t row_begin, row_end; /* rows [row_begin,row_end) are traced (multi-GPU row tiles) */
+    uint64_t time_ms;            /* (time * 1000).as_secs(), d3/entity/surface.rs:32 */
+    int32_t debug_crosshair;     /* context.debugging, universe/mod.rs:321-333 */
+    uint32_t reserved;
+} eu_frame;
+
+typedef struct {
+    uint64_t rays;               /* Universe::trace calls with depth > 0 (reach trace_closest) */
+    uint64_t bg_samples;         /* background().get_color calls */
+    uint64_t nan_pixels;         /* float->u8 casts of NaN (the reference would panic) */
+    uint64_t errors;             /* other would-panic conditions */
+} eu_stats;
+
+typedef struct {
+    int32_t dim;
+    uint32_t n_entities, n_shape_ops, n_leaves, n_materials, n_surfaces, n_color_ops, n_textures;
+    uint32_t hit_cap, list_depth, flat_bytes;
+} eu_scene_info;
+
+/* Texture decoding is not part of the hot path (image::open, scene.rs:1053,1065); the host
+ * supplies decoded RGBA8 texels (image::DynamicImage::get_pixel semantics: alpha 255 for RGB and
+ * Luma images, row 0 = top).  The callback allocates *rgba with eu_alloc(); the library frees it.
+ * Return 0 on success. */
+typedef int (*eu_texture_loader)(void *user, const char *path, uint32_t *width, uint32_t *height, uint8_t **rgba);
+
+typedef struct {
+    eu_texture_loader load_texture;
+    void *user;
+    uint32_t random_seed;        /* stands in for rand::random() in surface_color_perlin_hue_random_3 */
+    uint32_t reserved;
+} eu_load_opts;
+
+void *eu_alloc(size_t bytes);
+void eu_free(void *p);
+
+/* scene.rs:1466 Parser::default().parse::<Box<Environment>>(json) */
+int eu_scene_from_json(const char *json, size_t len, const eu_load_opts *opts, eu_scene **out, char *err, size_t errlen);
+void eu_scene_free(eu_scene *);
+int eu_scene_get_info(const eu_scene *, eu_scene_info *);
+int eu_scene_default_camera(const eu_scene *, eu_camera *out);      /* camera as loaded from the JSON */
+const void *eu_scene_flat(const eu_scene *, size_t *bytes);         /* flattened blob (flat_scene.h), for inspection */
+
+int eu_device_count(void);
+int eu_renderer_create(const eu_scene *, int device, eu_renderer **out, char *err, size_t errlen);
+void eu_renderer_destroy(eu_renderer *);
+
+/* Environment::render on the GPU, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
+ * rgba_dev: DEVICE buffer of (row_end-row_begin)*width uint32 (R | G<<8 | B<<16 | 255<<24), rows in
+ * the reference's order (row 0 first = bottom row on screen).  hit_t_dev: optional DEVICE buffer of
+ * (row_end-row_begin)*width doubles, distance of the primary ray's closest hit (-1 if none). */
+int eu_render_device(eu_renderer *, const eu_camera *, const eu_frame *, void *hip_stream, void *rgba_dev, double *hit_t_dev);
+/* RGBA8 -> packed RGB8 (RawImage2d<u8>, ClientFormat::U8U8U8, universe/mod.rs:351-356), device to device. */
+int eu_pack_rgb_device(eu_renderer *, const void *rgba_dev, void *rgb_dev, size_t pixels, void *hip_stream);
+/* Counters of the most recent eu_render_device on this renderer (waits for it to finish). */
+int eu_renderer_stats(eu_renderer *, eu_stats *);
+/* Duration of the most recent trace-kernel launch, measured with HIP events on its own stream. */
+int eu_renderer_kernel_ms(eu_renderer *, float *ms);
+
+/* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host. */
+int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
+/* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F>. */
+int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, int32_t x, int32_t y, double rgb[3]);
+
+/* Device self-test of the elementary functions (fn: 0 acos 1 asin 2 sin 3 cos 4 tan 5 atan2(x,y) 6 sqrt
+ * 7 x/y 8 fmod(x,y)); host buffers. */
+int eu_selftest_math(int device, int fn, const double *x, const double *y, double *out, size_t n);
+
+const char *eu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
