@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the per-pixel trace loop on MI355X (BASELINE.json metric).
+
+One "step" = one Environment::render pass: every pixel of the frame is traced by the HIP
+persistent-wavefront kernel (scene, textures and the output frame resident in HBM) and the
+RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
+
+  N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
+  N > 1 : the frame grows with N (weak scaling: 1920x1080 pixels per GPU, aspect kept, same
+          camera/fov), is cut into 8-row strips dealt round-robin over the ranks (row tiles),
+          each rank traces its strips, and ONE RCCL gather collects them on rank 0, which
+          restores row order and packs RGB8.
+
+Prints one JSON line (rank 0).  `value` = rays of all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="3d_room.json")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
+    return ap.parse_args()
+
+
+def frame_dims(w, h, n):
+    """Weak scaling: n times the pixels, aspect kept, multiples of 8."""
+    if n == 1:
+        return w, h
+    s = math.sqrt(n)
+    return 8 * int(round(w * s / 8.0)), 8 * int(round(h * s / 8.0))
+
+
+def cpu_baseline(scene_path, w, h, depth, sample_rows):
+    """The oracle (CPU restatement, kind "port") timed on this host's cores -- a reported baseline."""
+    from oracle.scene_loader import load_scene_file
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    osc = load_scene_file(scene_path)
+    if sample_rows and sample_rows < h:
+        r0 = (h - sample_rows) // 2
+        rows = (r0, r0 + sample_rows)
+        sample = "%s %dx%d depth %d, rows %d..%d (centre band), 1 run" % (os.path.basename(scene_path), w, h, depth, rows[0], rows[1])
+    else:
+        rows = None
+        sample = "%s %dx%d depth %d, whole frame, 1 run" % (os.path.basename(scene_path), w, h, depth)
+    t0 = time.perf_counter()
+    _, _, st = osc.render(w, h, max_depth=depth, threads=threads, rows=rows)
+    dt = time.perf_counter() - t0
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": sample, "seconds": round(dt, 3), "rays": st["rays"]}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if any."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            data = json.load(f)
+        return data.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n and world != 1:
+        n = world
+
+    import torch
+    import torch.distributed as dist
+    from euclider_amd import Parser
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the trace path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_path = os.path.join(ROOT, "scenes", args.scene)
+    env = Parser().parse_file(scene_path)
+    env.camera.max_depth = args.max_depth
+    W, H = frame_dims(args.width, args.height, world)
+    strips = (rank, world) if world > 1 else None
+    frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
+    local_rows = env.local_rows(frame)
+    if world > 1:      # equal counts for the gather: pad to the largest rank
+        t = torch.tensor([local_rows], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_rows = int(t.item())
+    else:
+        max_rows = local_rows
+
+    rgba = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gathered = None
+    perm = None
+    full = None
+    rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(rgba) for _ in range(world)]
+        rows = torch.arange(H, device=dev)
+        strip = rows // 8
+        perm = (strip % world) * max_rows + (strip // world) * 8 + (rows % 8)
+        full = torch.empty((H, W), dtype=torch.int32, device=dev)
+
+    def step():
+        env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
+        if world > 1:
+            dist.gather(rgba, gathered, dst=0)                      # the single RCCL gather
+            if rank == 0:
+                torch.index_select(torch.cat(gathered, 0), 0, perm, out=full)
+                env.pack_rgb_device(full.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
+        else:
+            env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    st = env.stats(device=local_rank)
+    kms = env.kernel_ms_history(min(args.steps, 64), device=local_rank)
+    tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays_per_step = tot[0].item()
+    elapsed = tmax.item()
+
+    if rank == 0:
+        value = rays_per_step * args.steps / elapsed / 1e6
+        kernel_ms = sum(kms) / max(1, len(kms))
+        # algorithmic bytes of ONE launch of the trace kernel on this rank (DESIGN.md "Roofline"):
+        # 4 B RGBA8 store per pixel + 16 B (4 RGBA8 texels) per background sample + the flat scene once
+        alg_bytes = 4.0 * local_rows * W + 16.0 * st["bg_samples"] + env.info.flat_bytes
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        workload = "%s %dx%d depth %d" % (args.scene, W, H, args.max_depth)
+        out = {
+            "metric": "Mray/s (primary+secondary) at 1920x1080 depth-8; frac of HBM roofline",
+            "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
+                       "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
+                       "would_panic_events": int(tot[2].item()),
+                       "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
+                       "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_traffic(workload), "kernel": "eu_trace_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": alg_bytes,
+                         "note": "f64-VALU/divergence bound by construction; HBM fraction reported because BASELINE asks for it"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows)
+            out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

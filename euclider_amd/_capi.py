@@ -26,7 +26,8 @@ class Camera(C.Structure):
 
 class Frame(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
-                ("time_ms", C.c_uint64), ("debug_crosshair", C.c_int32), ("reserved", C.c_uint32)]
+                ("time_ms", C.c_uint64), ("debug_crosshair", C.c_int32), ("strip_count", C.c_uint32),
+                ("strip_index", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -59,6 +60,7 @@ SYMBOLS = {
     "eu_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "eu_scene_default_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "eu_scene_flat": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "eu_frame_local_rows": (C.c_uint32, [C.POINTER(Frame)]),
     "eu_device_count": (C.c_int, []),
     "eu_renderer_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "eu_renderer_destroy": (None, [C.c_void_p]),
@@ -67,6 +69,7 @@ SYMBOLS = {
     "eu_pack_rgb_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "eu_renderer_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "eu_renderer_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "eu_renderer_kernel_ms_history": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "eu_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
                             C.POINTER(Stats)]),
     "eu_trace_screen_point": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_int32, C.c_int32,

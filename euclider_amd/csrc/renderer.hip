@@ -50,7 +50,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
     LaneCounters cnt = {0, 0, 0, 0};
 
     const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;
-    const uint32_t rows = fr.row_end - fr.row_begin;
+    const uint32_t rows = fr.local_rows;
 
     /* lane state */
     bool active = false;
@@ -82,7 +82,15 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 px_x = (tile % fr.tiles_x) * 8 + (within & 7);
                 ry = (tile / fr.tiles_x) * 8 + (within >> 3);
                 if (px_x >= fr.width || ry >= rows) continue;
-                px_y = fr.row_begin + ry;
+                if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
+                    const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
+                    px_y = fr.row_begin + gstrip * 8 + (ry & 7);
+                    if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
+                        rgba[ry * fr.width + px_x] = 0u;
+                        if (hit_t) hit_t[ry * fr.width + px_x] = -1.0;
+                        continue;
+                    }
+                } else px_y = fr.row_begin + ry;
                 out_idx = ry * fr.width + px_x;
             }
 
@@ -332,7 +340,9 @@ struct eu_renderer {
     uint8_t *d_rgb = nullptr;
     double *d_hit = nullptr;
     double *d_point = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    static constexpr int EV_RING = 64;        /* per-launch HIP event pairs, on the launch stream */
+    hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {};
+    unsigned long long launches = 0;
     hipStream_t last_stream = nullptr;
     bool have_timing = false;
     int num_cus = 0;
@@ -398,8 +408,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
         HIP_TRY(hipMemset(r->d_counters, 0, sizeof(EuDevCounters)));
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(double)));
-        HIP_TRY(hipEventCreate(&r->ev_start));
-        HIP_TRY(hipEventCreate(&r->ev_stop));
+        for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
         return EU_OK;
     };
     int rc = body();
@@ -418,8 +427,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (r->d_rgb) (void)hipFree(r->d_rgb);
     if (r->d_hit) (void)hipFree(r->d_hit);
     if (r->d_point) (void)hipFree(r->d_point);
-    if (r->ev_start) (void)hipEventDestroy(r->ev_start);
-    if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
+    for (int i = 0; i < eu_renderer::EV_RING; i++) { if (r->ev_start[i]) (void)hipEventDestroy(r->ev_start[i]); if (r->ev_stop[i]) (void)hipEventDestroy(r->ev_stop[i]); }
     delete r;
 }
 
@@ -473,15 +481,22 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     EuDevFrame df;
     memset(&df, 0, sizeof df);
     df.width = f->width; df.height = f->height; df.row_begin = f->row_begin; df.row_end = f->row_end;
-    const uint32_t rows = f->row_end - f->row_begin;
+    uint32_t rows = f->row_end - f->row_begin;
+    if (f->strip_count > 1) {
+        if (f->strip_index >= f->strip_count) { r->err = "strip_index >= strip_count"; return EU_ERR_INVALID_ARGUMENT; }
+        rows = eu_frame_local_rows(f);
+        df.strip_count = f->strip_count; df.strip_index = f->strip_index;
+    }
+    df.local_rows = rows;
     df.tiles_x = (f->width + 7) / 8;
     df.n_tiles = df.tiles_x * ((rows + 7) / 8);
     df.debug_crosshair = f->debug_crosshair ? 1u : 0u;
     df.time_s = (double)f->time_ms / 1000.0;
-    if (single) { df.single_pixel = 1; df.single_x = single_x; df.single_y = f->row_begin; df.tiles_x = 1; df.n_tiles = 1; }
+    if (single) { df.strip_count = 0; df.local_rows = 1; df.single_pixel = 1; df.single_x = single_x; df.single_y = f->row_begin; df.tiles_x = 1; df.n_tiles = 1; }
     if (rows == 0) return EU_OK;
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, sizeof(EuDevCounters), stream));
-    HIP_TRY(hipEventRecord(r->ev_start, stream));
+    const int slot = (int)(r->launches % eu_renderer::EV_RING);
+    HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
     hipError_t e;
     const bool big = r->hit_cap > 32;
     if (r->dim == 3) {
@@ -492,10 +507,21 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
         else e = launch_trace<4, 96, false>(r, stream, dc, df, rgba, hit_t, point);
     }
     if (e != hipSuccess) { r->err = std::string("kernel launch: ") + hipGetErrorString(e); return EU_ERR_HIP; }
-    HIP_TRY(hipEventRecord(r->ev_stop, stream));
+    HIP_TRY(hipEventRecord(r->ev_stop[slot], stream));
+    r->launches++;
     r->last_stream = stream;
     r->have_timing = true;
     return EU_OK;
+}
+
+extern "C" uint32_t eu_frame_local_rows(const eu_frame *f) {
+    if (!f || f->row_begin > f->row_end) return 0;
+    const uint32_t rows = f->row_end - f->row_begin;
+    if (f->strip_count <= 1) return rows;
+    const uint32_t strips = (rows + 7) / 8;                       /* strips of 8 rows over [row_begin,row_end) */
+    if (f->strip_index >= f->strip_count) return 0;
+    const uint32_t mine = (strips + f->strip_count - 1 - f->strip_index) / f->strip_count;   /* strips s with s % count == index */
+    return mine * 8;                                              /* padded: rows past row_end are left untouched */
 }
 
 extern "C" int eu_render_device(eu_renderer *r, const eu_camera *cam, const eu_frame *f, void *hip_stream, void *rgba_dev, double *hit_t_dev) {
@@ -523,11 +549,20 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
 }
 
 extern "C" int eu_renderer_kernel_ms(eu_renderer *r, float *ms) {
-    if (!r || !ms || !r->have_timing) return EU_ERR_INVALID_ARGUMENT;
+    return eu_renderer_kernel_ms_history(r, ms, 1) == 1 ? EU_OK : EU_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int eu_renderer_kernel_ms_history(eu_renderer *r, float *ms, int max_n) {
+    if (!r || !ms || max_n < 1) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipEventSynchronize(r->ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms, r->ev_start, r->ev_stop));
-    return EU_OK;
+    unsigned long long have = r->launches < (unsigned long long)eu_renderer::EV_RING ? r->launches : (unsigned long long)eu_renderer::EV_RING;
+    int n = (int)(have < (unsigned long long)max_n ? have : (unsigned long long)max_n);
+    for (int i = 0; i < n; i++) {
+        const int slot = (int)((r->launches - (unsigned long long)n + (unsigned long long)i) % eu_renderer::EV_RING);
+        HIP_TRY(hipEventSynchronize(r->ev_stop[slot]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], r->ev_start[slot], r->ev_stop[slot]));
+    }
+    return n;
 }
 
 static int ensure_buffers(eu_renderer *r, size_t pixels, bool want_hit) {
@@ -547,7 +582,7 @@ static int ensure_buffers(eu_renderer *r, size_t pixels, bool want_hit) {
 extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, double *hit_t_host, eu_stats *stats) {
     if (!r || !cam || !f || !rgb_host) return EU_ERR_INVALID_ARGUMENT;
     if (f->row_begin > f->row_end || f->row_end > f->height) return EU_ERR_INVALID_ARGUMENT;
-    const size_t pixels = (size_t)(f->row_end - f->row_begin) * f->width;
+    const size_t pixels = (size_t)eu_frame_local_rows(f) * f->width;
     if (pixels == 0) { if (stats) memset(stats, 0, sizeof *stats); return EU_OK; }
     HIP_TRY(hipSetDevice(r->device));
     int rc = ensure_buffers(r, pixels, hit_t_host != nullptr);

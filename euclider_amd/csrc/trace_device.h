@@ -45,6 +45,7 @@ struct EuDevFrame {
     uint32_t width, height, row_begin, row_end;
     uint32_t tiles_x, n_tiles, debug_crosshair, single_pixel;
     uint32_t single_x, single_y;
+    uint32_t local_rows, strip_count, strip_index, pad;   /* rows in the output buffer; interleaved-strip partition */
     double time_s;          /* time_millis, d3/entity/surface.rs:32 */
 };
 

@@ -96,9 +96,17 @@ class Environment:
     def max_depth(self):
         return self.camera.max_depth
 
-    def _frame(self, width, height, time_ms, debugging, rows=None):
+    def _frame(self, width, height, time_ms, debugging, rows=None, strips=None):
         r0, r1 = rows if rows is not None else (0, height)
-        return _capi.Frame(width, height, r0, r1, time_ms, 1 if debugging else 0, 0)
+        index, count = strips if strips is not None else (0, 0)
+        return _capi.Frame(width, height, r0, r1, time_ms, 1 if debugging else 0, count, index, 0)
+
+    def frame(self, width, height, time=0.0, debugging=False, rows=None, strips=None):
+        return self._frame(width, height, _duration_to_ms(time), debugging, rows, strips)
+
+    @staticmethod
+    def local_rows(frame):
+        return _capi.lib().eu_frame_local_rows(C.byref(frame))
 
     def trace_screen_point(self, time, max_depth, screen_x, screen_y, screen_width, screen_height, debug=False, device=0):
         cam = _capi.Camera.from_buffer_copy(self.camera)
@@ -110,14 +118,14 @@ class Environment:
             raise EuError(rc)
         return tuple(rgb)
 
-    def render(self, dimensions, time=0.0, threads=0, context=None, device=0, want_hit_t=False, rows=None):
+    def render(self, dimensions, time=0.0, threads=0, context=None, device=0, want_hit_t=False, rows=None, strips=None):
         """Environment::render.  `threads` is accepted for signature parity and ignored (the GPU
         kernel replaces the thread pool).  Returns RawImage2d; `.stats` and `.hit_t` are extras."""
         context = context or SimulationContext()
         width, height = dimensions
         bw, bh = width // context.resolution, height // context.resolution     # universe/mod.rs:308-309
-        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows)
-        nrows = fr.row_end - fr.row_begin
+        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, strips)
+        nrows = self.local_rows(fr)
         rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
         hit = np.zeros((nrows, bw), dtype=np.float64) if want_hit_t else None
         st = _capi.Stats()
@@ -150,6 +158,19 @@ class Environment:
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return ms.value
+
+
+    def kernel_ms_history(self, n, device=0):
+        buf = (C.c_float * max(1, n))()
+        got = _capi.lib().eu_renderer_kernel_ms_history(self.renderer(device), buf, n)
+        if got < 0:
+            raise EuError(got)
+        return [buf[i] for i in range(got)]
+
+    def pack_rgb_device(self, rgba_ptr, rgb_ptr, pixels, stream=None, device=0):
+        rc = _capi.lib().eu_pack_rgb_device(self.renderer(device), rgba_ptr, rgb_ptr, pixels, stream)
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
 
 
 class Parser:

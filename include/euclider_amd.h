@@ -49,12 +49,19 @@ typedef struct {
     double location[4], forward[4], up[4], left[4];
 } eu_camera;
 
-/* One frame = Environment::render's arguments (universe/mod.rs:300-311). */
+/* One frame = Environment::render's arguments (universe/mod.rs:300-311), plus the multi-GPU partition.
+ * Partition: with strip_count <= 1 the renderer traces rows [row_begin,row_end) into a buffer of
+ * (row_end-row_begin) rows.  With strip_count = N > 1 the rows [row_begin,row_end) are cut into 8-row
+ * strips and this renderer traces the strips s with s % N == strip_index (row tiles dealt round-robin,
+ * so that glass objects, which cost hundreds of rays per pixel, are spread over all GPUs); its buffer
+ * holds eu_frame_local_rows() rows: local row (s / N) * 8 + (row % 8). */
 typedef struct {
     uint32_t width, height;      /* buffer dimensions (window / context.resolution) */
-    uint32_t row_begin, row_end; /* rows [row_begin,row_end) are traced (multi-GPU row tiles) */
+    uint32_t row_begin, row_end;
     uint64_t time_ms;            /* (time * 1000).as_secs(), d3/entity/surface.rs:32 */
     int32_t debug_crosshair;     /* context.debugging, universe/mod.rs:321-333 */
+    uint32_t strip_count;        /* 0 or 1: contiguous rows */
+    uint32_t strip_index;
     uint32_t reserved;
 } eu_frame;
 
@@ -94,14 +101,16 @@ int eu_scene_get_info(const eu_scene *, eu_scene_info *);
 int eu_scene_default_camera(const eu_scene *, eu_camera *out);      /* camera as loaded from the JSON */
 const void *eu_scene_flat(const eu_scene *, size_t *bytes);         /* flattened blob (flat_scene.h), for inspection */
 
+uint32_t eu_frame_local_rows(const eu_frame *);   /* rows of the output buffer for this frame/partition */
+
 int eu_device_count(void);
 int eu_renderer_create(const eu_scene *, int device, eu_renderer **out, char *err, size_t errlen);
 void eu_renderer_destroy(eu_renderer *);
 
 /* Environment::render on the GPU, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
- * rgba_dev: DEVICE buffer of (row_end-row_begin)*width uint32 (R | G<<8 | B<<16 | 255<<24), rows in
+ * rgba_dev: DEVICE buffer of eu_frame_local_rows()*width uint32 (R | G<<8 | B<<16 | 255<<24), rows in
  * the reference's order (row 0 first = bottom row on screen).  hit_t_dev: optional DEVICE buffer of
- * (row_end-row_begin)*width doubles, distance of the primary ray's closest hit (-1 if none). */
+ * eu_frame_local_rows()*width doubles, distance of the primary ray's closest hit (-1 if none). */
 int eu_render_device(eu_renderer *, const eu_camera *, const eu_frame *, void *hip_stream, void *rgba_dev, double *hit_t_dev);
 /* RGBA8 -> packed RGB8 (RawImage2d<u8>, ClientFormat::U8U8U8, universe/mod.rs:351-356), device to device. */
 int eu_pack_rgb_device(eu_renderer *, const void *rgba_dev, void *rgb_dev, size_t pixels, void *hip_stream);
@@ -109,6 +118,8 @@ int eu_pack_rgb_device(eu_renderer *, const void *rgba_dev, void *rgb_dev, size_
 int eu_renderer_stats(eu_renderer *, eu_stats *);
 /* Duration of the most recent trace-kernel launch, measured with HIP events on its own stream. */
 int eu_renderer_kernel_ms(eu_renderer *, float *ms);
+/* The same for the most recent min(max_n, 64) launches, oldest first; returns how many were written. */
+int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
 
 /* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host. */
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
