@@ -9,7 +9,8 @@
  * wave reads the same record at the same time (LDS broadcast, no bank conflicts).
  *
  *  - shapes      : each entity's CSG tree in POST-ORDER ("shape program"); op i's subtree is
- *                  ops[first..i]; composite children: b = i-1, a = ops[b].first-1.
+ *                  ops[first..i]; composite children: b = i-1, a = ops[b].first-1.  Half-space
+ *                  chains are collapsed into single ops (EU_SH_CHAIN_*).
  *  - materials   : Vacuum | LinearSpace (list of per-component RPN programs compiled from the
  *                  meval expressions, material.rs:59-163)
  *  - surfaces    : ComposableSurface = ratio/direction provider ids + a post-order colour program
@@ -27,8 +28,14 @@
 
 enum EuShapeKind : uint32_t {
     EU_SH_VOID = 0, EU_SH_SPHERE = 1, EU_SH_PLANE = 2, EU_SH_HALFSPACE = 3, EU_SH_CYLINDER = 4,
-    EU_SH_UNION = 8, EU_SH_INTERSECTION = 9, EU_SH_COMPLEMENT = 10, EU_SH_SYMDIFF = 11
+    EU_SH_UNION = 8, EU_SH_INTERSECTION = 9, EU_SH_COMPLEMENT = 10, EU_SH_SYMDIFF = 11,
+    /* a left-fold Union / Intersection whose leaves are all half-spaces or hyperplanes (cuboid,
+     * hypercuboid, wall sets), collapsed into ONE op: `count` leaves, parameters contiguous with
+     * stride 2*D+2 (HALFSPACE layout; a Hyperplane is stored with signum = NaN, nflip = n).
+     * Behaves like a leaf that produces up to `count` hits. */
+    EU_SH_CHAIN_UNION = 16, EU_SH_CHAIN_INTERSECTION = 17
 };
+#define EU_CHAIN_MAX 8
 enum EuMaterialKind : uint32_t { EU_MAT_VACUUM = 0, EU_MAT_LINEAR = 1 };
 enum EuRatioKind : uint32_t { EU_RATIO_UNIFORM = 0, EU_RATIO_FRESNEL = 1 };
 enum EuThresholdKind : uint32_t { EU_THR_IDENTITY = 0, EU_THR_SNELL = 1 };
@@ -71,7 +78,7 @@ struct EuFlatHeader {
  *   CYLINDER  c[D], axis[D] (normalised), r, r*r                                           */
 struct EuShapeOp {
     uint8_t kind;
-    uint8_t reserved;
+    uint8_t count;       /* chain ops: number of leaves (2..EU_CHAIN_MAX) */
     uint16_t first;      /* index (within the ops table) of the first op of this subtree */
     uint32_t param;      /* word offset into the params table */
 };

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/euclider_amd.h"
@@ -30,22 +31,32 @@
 #define EU_BLOCK 256
 
 /* ------------------------------------------------------------------ the lane state machine */
-template <int D, int CAP, bool SCENE_IN_LDS>
-__global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words,
+template <int D, int HSCAP /* 0: hit stack in LDS (capacity = hs_cap), else private array of HSCAP */, bool SCENE_IN_LDS>
+__global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap,
                                                             EuDevCamera cam, EuDevFrame fr, EuDevCounters *counters,
                                                             uint32_t *__restrict__ rgba, double *__restrict__ hit_t,
                                                             double *__restrict__ point_rgb /* single-pixel mode: un-quantised Rgb<F> */) {
-    extern __shared__ uint64_t lds_scene[];
+    extern __shared__ uint64_t lds_dyn[];
     const uint64_t *base = scene_g;
+    uint32_t lds_words = 0;
     if (SCENE_IN_LDS) {
-        for (uint32_t i = threadIdx.x; i < scene_words; i += blockDim.x) lds_scene[i] = scene_g[i];
+        for (uint32_t i = threadIdx.x; i < scene_words; i += blockDim.x) lds_dyn[i] = scene_g[i];
         __syncthreads();
-        base = lds_scene;
+        base = lds_dyn;
+        lds_words = scene_words;
     }
     EuScene S;
     S.init(base);
 
-    HitStack<D, CAP> HS;
+    typename std::conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
+    if constexpr (HSCAP == 0) {
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        double *hs_t = (double *)(lds_dyn + lds_words);
+        uint32_t *hs_c = (uint32_t *)(hs_t + (EU_BLOCK / 64) * hs_cap * 64);
+        HS.t = hs_t + wave * hs_cap * 64 + lane;
+        HS.c = hs_c + wave * hs_cap * 64 + lane;
+        HS.cap = hs_cap;
+    }
     FrameStack<D> FS;
     LaneCounters cnt = {0, 0, 0, 0};
 
@@ -146,10 +157,10 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 for (uint32_t e = 0; e < S.n_entities; e++) {
                     const EuFlatEntity *E = S.entity(e);
                     if (E->surface < 0) continue;
-                    const uint32_t n = eval_shape<D, CAP>(S, E->shape_first, E->shape_root, o, d, HS, cnt);
+                    double t = 0.0; uint32_t code = 0;
+                    const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
                     if (n == 0) continue;
-                    const double t = HS.t[0];
-                    if (!have || best_t > t) { have = true; best_t = t; best_code = HS.c[0]; best_ent = e; }
+                    if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
             }
             if (primary) { first_hit = have ? best_t : -1.0; primary = false; }
@@ -452,10 +463,12 @@ static int make_dev_camera(const eu_camera *cam, const eu_frame *f, EuDevCamera 
     return EU_OK;
 }
 
-template <int D, int CAP, bool LDS>
+template <int D, int HSCAP, bool LDS>
 static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
-    auto kern = eu_trace_kernel<D, CAP, LDS>;
-    const size_t lds_bytes = LDS ? (size_t)r->scene_words * 8 : 0;
+    auto kern = eu_trace_kernel<D, HSCAP, LDS>;
+    const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap < 4 ? 4u : ((r->hit_cap + 3u) & ~3u));
+    size_t lds_bytes = LDS ? (size_t)r->scene_words * 8 : 0;
+    if (HSCAP == 0) lds_bytes += (size_t)(EU_BLOCK / 64) * hs_cap * 64 * 12;
     int blocks_per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, EU_BLOCK, lds_bytes);
     if (e != hipSuccess) return e;
@@ -465,7 +478,7 @@ static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCa
     unsigned long long grid = (unsigned long long)r->num_cus * (unsigned long long)blocks_per_cu;
     if (grid > want_blocks) grid = want_blocks;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(EU_BLOCK), lds_bytes, stream, r->d_scene, r->scene_words, dc, df, r->d_counters, rgba, hit_t, point);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(EU_BLOCK), lds_bytes, stream, r->d_scene, r->scene_words, hs_cap, dc, df, r->d_counters, rgba, hit_t, point);
     return hipGetLastError();
 }
 
@@ -498,12 +511,15 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     const int slot = (int)(r->launches % eu_renderer::EV_RING);
     HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
     hipError_t e;
-    const bool big = r->hit_cap > 32;
+    /* hit stack in LDS when the scene's static bound is small (16 entries * 12 B * 256 lanes = 48 KB per block) */
+    const bool hs_lds = r->hit_cap <= 32 && r->scene_in_lds;
     if (r->dim == 3) {
-        if (r->scene_in_lds) e = big ? launch_trace<3, 96, true>(r, stream, dc, df, rgba, hit_t, point) : launch_trace<3, 32, true>(r, stream, dc, df, rgba, hit_t, point);
+        if (hs_lds) e = launch_trace<3, 0, true>(r, stream, dc, df, rgba, hit_t, point);
+        else if (r->scene_in_lds) e = launch_trace<3, 96, true>(r, stream, dc, df, rgba, hit_t, point);
         else e = launch_trace<3, 96, false>(r, stream, dc, df, rgba, hit_t, point);
     } else {
-        if (r->scene_in_lds) e = big ? launch_trace<4, 96, true>(r, stream, dc, df, rgba, hit_t, point) : launch_trace<4, 32, true>(r, stream, dc, df, rgba, hit_t, point);
+        if (hs_lds) e = launch_trace<4, 0, true>(r, stream, dc, df, rgba, hit_t, point);
+        else if (r->scene_in_lds) e = launch_trace<4, 96, true>(r, stream, dc, df, rgba, hit_t, point);
         else e = launch_trace<4, 96, false>(r, stream, dc, df, rgba, hit_t, point);
     }
     if (e != hipSuccess) { r->err = std::string("kernel launch: ") + hipGetErrorString(e); return EU_ERR_HIP; }

@@ -709,13 +709,50 @@ struct Flattener {
     std::map<const void *, uint32_t> mat_ids, surf_ids, mapped_ids;
     uint32_t hit_cap = 0, list_depth = 0, color_depth = 0, rpn_depth = 0, n_leaves = 0;
 
+    static bool is_flat_leaf(const Shape &s) { return s.kind == Shape::HalfSpace || s.kind == Shape::Hyperplane; }
+
+    /* left-fold chain of half-space / hyperplane leaves with one Union or Intersection operation
+     * (ComposableShape::of, shape.rs:523-545): collects the leaves in fold order */
+    static bool collect_chain(const Shape &s, SetOperation op, std::vector<const Shape *> &leaves) {
+        if (is_flat_leaf(s)) { leaves.push_back(&s); return true; }
+        if (s.kind != Shape::ComposableShape || s.operation != op || !is_flat_leaf(*s.sb)) return false;
+        if (!collect_chain(*s.sa, op, leaves)) return false;
+        leaves.push_back(s.sb.get());
+        return true;
+    }
+
+    void push_halfspace_params(const Shape &s) {
+        for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+        params.push_back(s.r);
+        if (s.kind == Shape::HalfSpace) {
+            params.push_back(s.signum);
+            double k = -s.signum;                                   /* shape.rs:860 normal *= -signum */
+            for (int i = 0; i < D; i++) params.push_back(s.a[i] * k);
+        } else {                                                    /* Hyperplane: never "inside", normal as given */
+            params.push_back(std::nan(""));
+            for (int i = 0; i < D; i++) params.push_back(s.a[i]);
+        }
+    }
+
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
     uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
         op.first = (uint16_t)ops.size();
         uint32_t len = 0;
-        if (s.kind == Shape::ComposableShape) {
+        std::vector<const Shape *> chain;
+        if (s.kind == Shape::ComposableShape && (s.operation == SetOperation::Union || s.operation == SetOperation::Intersection) &&
+            collect_chain(s, s.operation, chain) && chain.size() >= 2 && chain.size() <= EU_CHAIN_MAX) {
+            op.kind = (uint8_t)(s.operation == SetOperation::Union ? EU_SH_CHAIN_UNION : EU_SH_CHAIN_INTERSECTION);
+            op.count = (uint8_t)chain.size();
+            op.param = (uint32_t)params.size();
+            for (auto *leaf : chain) push_halfspace_params(*leaf);
+            n_leaves += (uint32_t)chain.size();
+            len = (uint32_t)chain.size();
+            uint32_t use = base_use + len;
+            if (use > hit_cap) hit_cap = use;
+            if (depth + 1 > list_depth) list_depth = depth + 1;
+        } else if (s.kind == Shape::ComposableShape) {
             uint32_t la = emit_shape(*s.sa, base_use, depth);
             uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1);
             len = la + lb;
@@ -739,14 +776,10 @@ struct Flattener {
                 for (int i = 0; i < D; i++) params.push_back(s.a[i]);
                 params.push_back(s.r);
                 break;
-            case Shape::HalfSpace: {
+            case Shape::HalfSpace:
                 op.kind = EU_SH_HALFSPACE; len = 1;
-                for (int i = 0; i < D; i++) params.push_back(s.a[i]);
-                params.push_back(s.r); params.push_back(s.signum);
-                double k = -s.signum;                                   /* shape.rs:860 normal *= -signum */
-                for (int i = 0; i < D; i++) params.push_back(s.a[i] * k);
+                push_halfspace_params(s);
                 break;
-            }
             default:
                 op.kind = EU_SH_CYLINDER; len = 2;
                 for (int i = 0; i < D; i++) params.push_back(s.a[i]);

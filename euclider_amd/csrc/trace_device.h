@@ -70,9 +70,9 @@ struct EuScene {
     }
     EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
     EU_DEV double dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
-    EU_DEV void op(uint32_t i, uint32_t &kind, uint32_t &first, uint32_t &param) const {
+    EU_DEV void op(uint32_t i, uint32_t &kind, uint32_t &first, uint32_t &param, uint32_t &count) const {
         uint64_t x = w[off_ops + i];
-        kind = (uint32_t)(x & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
+        kind = (uint32_t)(x & 0xff); count = (uint32_t)((x >> 8) & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
     }
     EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params + off); }
     EU_DEV const EuFlatEntity *entity(uint32_t e) const { return (const EuFlatEntity *)(w + off_entities + 2 * e); }
@@ -199,14 +199,33 @@ template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const d
     }
 }
 
+/* ---- half-space chains (EU_SH_CHAIN_*): all leaves of a left-fold Union / Intersection are planes ---- */
+#define EU_HS_STRIDE(D) (2 * (D) + 2)
+
+template <int D> EU_DEV bool chain_inside(bool is_union, uint32_t n, const double *P, const double *p) {
+    bool acc = !is_union;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        if (k < n) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double r = vdot<D>(Pk, p) + Pk[D];
+            const bool in = (Pk[D + 1] == rust_signum(r));          /* shape.rs:874-880 */
+            acc = is_union ? (acc || in) : (acc && in);             /* shape.rs:591-594, no short-circuit needed: pure */
+        }
+    }
+    return acc;
+}
+
 /* is_point_inside of the subtree ops[first..root] (shape.rs:589-600), evaluated without
  * short-circuit on a bit stack (the leaf tests are pure, so the result is the same) */
 template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, uint32_t root, const double *p) {
     uint64_t st = 0;
     for (uint32_t i = first; i <= root; i++) {
-        uint32_t kind, f, param;
-        S.op(i, kind, f, param);
-        if (kind < EU_SH_UNION) {
+        uint32_t kind, f, param, cnt;
+        S.op(i, kind, f, param, cnt);
+        if (kind >= EU_SH_CHAIN_UNION) {
+            st = (st << 1) | (chain_inside<D>(kind == EU_SH_CHAIN_UNION, cnt, S.params(param), p) ? 1ull : 0ull);
+        } else if (kind < EU_SH_UNION) {
             st = (st << 1) | (leaf_inside<D>(kind, S.params(param), p) ? 1ull : 0ull);
         } else {
             uint64_t b = st & 1, a = (st >> 1) & 1;
@@ -220,13 +239,25 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
 }
 
 /* ------------------------------------------------------------------ per-lane state */
-/* hit code: bits 0..23 op index of the leaf, bit 30 = second root of the leaf, bit 31 = normal flipped */
+/* hit code: bits 0..15 op index, bits 16..23 leaf index inside a chain op, bit 30 = second root of
+ * the leaf, bit 31 = normal flipped */
 #define EU_HIT_SECOND 0x40000000u
 #define EU_HIT_FLIP 0x80000000u
 
-template <int D, int CAP> struct HitStack {
-    double t[CAP];
-    uint32_t c[CAP];
+/* the per-lane hit stack: in LDS (lane-interleaved: entry k of lane l at [k*64 + l], conflict-free
+ * ds_read/ds_write_b64) when the scene's static bound fits, else in private (scratch) memory */
+struct HitStackLds {
+    double *t; uint32_t *c; uint32_t cap;
+    EU_DEV double gt(uint32_t k) const { return t[k * 64]; }
+    EU_DEV uint32_t gc(uint32_t k) const { return c[k * 64]; }
+    EU_DEV void set(uint32_t k, double tt, uint32_t cc) { t[k * 64] = tt; c[k * 64] = cc; }
+};
+template <int CAP> struct HitStackPriv {
+    double t[CAP]; uint32_t c[CAP];
+    static constexpr uint32_t cap = CAP;
+    EU_DEV double gt(uint32_t k) const { return t[k]; }
+    EU_DEV uint32_t gc(uint32_t k) const { return c[k]; }
+    EU_DEV void set(uint32_t k, double tt, uint32_t cc) { t[k] = tt; c[k] = cc; }
 };
 
 enum { FR_OVER = 0, FR_TRANS_THEN_REFL = 1, FR_COMBINE = 2 };
@@ -242,30 +273,143 @@ struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
 
 struct Rgba { double r, g, b, a; };
 
+/* ------------------------------------------------------------------ half-space chains: exact, branch-light evaluation
+ *
+ * A cuboid is Intersection(((((h0,h1),h2),h3),h4),h5) (d3/entity/shape.rs:17-66); the reference runs
+ * five nested IntersectionIterators over lazily cached one-element streams (shape.rs:291-340).  For a
+ * chain every leaf yields at most one hit, so the whole cascade is a function of three small bit
+ * matrices, all computed with wave-uniform control flow:
+ *    present[k]           hit k exists              (!(t_k < 0), shape.rs:792)
+ *    LT[k] bit a          t_a < t_k                 (the "closer" test, ties/NaN go to b: shape.rs:226,304)
+ *    IN[k] bit a          leaf k contains hit a     (further_shape.is_point_inside, shape.rs:236,316)
+ * Level k merges the running stream S_{k-1} (an ordered list of leaf indices, 4 bits each) with the
+ * single hit of leaf k, reproducing the iterator's three modes: both present (a failed test skips),
+ * only a left (a failed test ends the stream), only b left. */
+template <int D>
+EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const double *o, const double *d,
+                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out) {
+    uint32_t pres = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        tk[k] = 0.0;
+        if (k < n) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
+            tk[k] = t;
+            if (!(t < 0.0)) pres |= 1u << k;
+        }
+    }
+    uint32_t in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
+        if (i < n) {
+            double loc[D];
+#pragma unroll
+            for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * tk[i];
+#pragma unroll
+            for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
+                if (j < n && j != i) {
+                    const double *Pj = P + j * EU_HS_STRIDE(D);
+                    const double r = vdot<D>(Pj, loc) + Pj[D];
+                    if (Pj[D + 1] == rust_signum(r)) in_k[j] |= 1u << i;
+                    if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
+                }
+            }
+        }
+    }
+    /* inside_of_A(h_k): Intersection -> all earlier leaves contain it, Union -> any (shape.rs:591-594) */
+    uint32_t list = 0, len = 0;
+    if (pres & 1u) { list = 0; len = 1; }
+#pragma unroll
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) {
+        if (k < n) {
+            bool all = true, any = false;
+#pragma unroll
+            for (uint32_t j = 0; j < k; j++) { const bool in = (in_k[j] >> k) & 1u; all = all && in; any = any || in; }
+            const bool bpass = is_union ? !any : all;
+            bool bpend = (pres >> k) & 1u, term = false;
+            uint32_t out = 0, olen = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < k; p++) {
+                if (p < len && !term) {
+                    const uint32_t a = (list >> (4 * p)) & 15u;
+                    if (bpend && !((lt_k[k] >> a) & 1u)) {          /* b is closer (or tie / NaN): it goes first */
+                        bpend = false;
+                        if (bpass) { out |= k << (4 * olen); olen++; }
+                    }
+                    const bool in = (in_k[k] >> a) & 1u;
+                    if (in != is_union) { out |= a << (4 * olen); olen++; }
+                    else if (!bpend) term = true;                   /* only a left and it fails: stream ends */
+                }
+            }
+            if (bpend && !term && bpass) { out |= k << (4 * olen); olen++; }
+            list = out; len = olen;
+        }
+    }
+    list_out = list;
+    return len;
+}
+
+EU_DEV double chain_t(const double (&tk)[EU_CHAIN_MAX], uint32_t idx) {
+    double t = tk[0];
+#pragma unroll
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (idx == k) t = tk[k];
+    return t;
+}
+
 /* ------------------------------------------------------------------ CSG: eager post-order evaluation */
-/* Evaluates entity shape program ops[first..root] for ray (o, d).  On return the entity's hit
- * stream is HS[0 .. n); returns n (only element 0 is used by trace_closest, universe/mod.rs:114). */
-template <int D, int CAP>
+/* Evaluates entity shape program ops[first..root] for ray (o, d); returns the number of hits of the
+ * entity's stream and its first element (only that is used by trace_closest, universe/mod.rs:114). */
+template <int D, class HS>
 EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
-                           HitStack<D, CAP> &HS, LaneCounters &cnt) {
+                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c) {
+    if (first == root) {   /* a bare leaf or chain: no list machinery */
+        uint32_t kind, f, param, count;
+        S.op(root, kind, f, param, count);
+        if (kind >= EU_SH_CHAIN_UNION) {
+            double tk[EU_CHAIN_MAX]; uint32_t list;
+            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            if (n) { first_t = chain_t(tk, list & 15u); first_c = root | ((list & 15u) << 16); }
+            return n;
+        }
+        double t0 = 0.0, t1 = 0.0;
+        const int n = leaf_hits<D>(kind, S.params(param), o, d, t0, t1);
+        if (n) { first_t = t0; first_c = root; }
+        return (uint32_t)n;
+    }
+    const uint32_t CAP = hs.cap;
     uint32_t sp = 0;          /* entries in use */
     uint64_t lens = 0;        /* stack of list lengths, 8 bits each (bit 7: stream repeats its last element forever) */
     for (uint32_t i = first; i <= root; i++) {
-        uint32_t kind, f, param;
-        S.op(i, kind, f, param);
+        uint32_t kind, f, param, count;
+        S.op(i, kind, f, param, count);
+        if (kind >= EU_SH_CHAIN_UNION) {
+            double tk[EU_CHAIN_MAX]; uint32_t list;
+            uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            if (sp + n > CAP) { cnt.errors++; n = 0; }
+            for (uint32_t p = 0; p < n; p++) {
+                const uint32_t idx = (list >> (4 * p)) & 15u;
+                hs.set(sp + p, chain_t(tk, idx), i | (idx << 16));
+            }
+            sp += n;
+            lens = (lens << 8) | (uint64_t)n;
+            continue;
+        }
         if (kind < EU_SH_UNION) {
             double t0 = 0.0, t1 = 0.0;
             int n = leaf_hits<D>(kind, S.params(param), o, d, t0, t1);
             if (sp + 2 > CAP) { cnt.errors++; n = 0; }
-            if (n >= 1) { HS.t[sp] = t0; HS.c[sp] = i; }
-            if (n >= 2) { HS.t[sp + 1] = t1; HS.c[sp + 1] = i | EU_HIT_SECOND; }
+            if (n >= 1) hs.set(sp, t0, i);
+            if (n >= 2) hs.set(sp + 1, t1, i | EU_HIT_SECOND);
             sp += (uint32_t)n;
             lens = (lens << 8) | (uint64_t)n;
             continue;
         }
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
-        uint32_t kb, fb, pb;
-        S.op(i - 1, kb, fb, pb);
+        uint32_t kb, fb, pb, cb_;
+        S.op(i - 1, kb, fb, pb, cb_);
         const uint32_t ra = fb - 1, fa = f, rb = i - 1;
         const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
         lens >>= 16;
@@ -280,12 +424,12 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if (!sa && !sb) break;
             if (guard >= guard_max || o0 + no >= CAP) { cnt.errors++; break; }   /* runaway (reference would spin) / capacity */
             double ta = 0.0, tb = 0.0; uint32_t ca = 0, cb = 0;
-            if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = HS.t[k]; ca = HS.c[k]; }
-            if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = HS.t[k]; cb = HS.c[k]; }
+            if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
+            if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
             const bool both = sa && sb;
             const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
             if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
-                HS.t[o0 + no] = ta; HS.c[o0 + no] = ca; no++;
+                hs.set(o0 + no, ta, ca); no++;
                 out_rep = true;
                 break;
             }
@@ -316,23 +460,26 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
                 if (ins) c ^= EU_HIT_FLIP;
                 break;
             }
-            if (emit) { HS.t[o0 + no] = t; HS.c[o0 + no] = c; no++; }
+            if (emit) { hs.set(o0 + no, t, c); no++; }
             if (end) break;
             if (stuck) { if (emit) out_rep = true; else cnt.errors++; break; }   /* no output forever: the reference would spin */
         }
-        for (uint32_t k = 0; k < no; k++) { HS.t[a0 + k] = HS.t[o0 + k]; HS.c[a0 + k] = HS.c[o0 + k]; }
+        for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
         sp = a0 + no;
         lens = (lens << 8) | (uint64_t)(no | (out_rep ? 0x80u : 0u));
     }
-    return (uint32_t)(lens & 0x7f);
+    const uint32_t n = (uint32_t)(lens & 0x7f);
+    if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
+    return n;
 }
 
 /* normal of the hit described by `code` at parameter t (recomputed from the leaf) */
 template <int D>
 EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const double *d, const double *loc, double *n) {
-    uint32_t kind, f, param;
-    S.op(code & 0xffffffu, kind, f, param);
+    uint32_t kind, f, param, count;
+    S.op(code & 0xffffu, kind, f, param, count);
     const double *P = S.params(param);
+    if (kind >= EU_SH_CHAIN_UNION) { P += ((code >> 16) & 0xffu) * EU_HS_STRIDE(D); kind = EU_SH_HALFSPACE; }
     switch (kind) {
     case EU_SH_SPHERE: {                                  /* shape.rs:708-709 */
         double v[D];
@@ -386,7 +533,7 @@ EU_DEV double pow_int(double x, double y) {   /* meval powf restricted to integr
     return (y < 0.0) ? 1.0 / r : r;
 }
 
-template <int D> EU_DEV double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
+template <int D> __device__ __noinline__ double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
     uint32_t off = (uint32_t)prog, len = (uint32_t)(prog >> 32);
     double st[8];
     int sp = 0;
