@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -27,280 +28,8 @@
 #include "../../include/euclider_amd.h"
 #include "scene_host.hpp"
 #include "trace_device.h"
-
-#define EU_BLOCK 256
-
-/* ------------------------------------------------------------------ the lane state machine */
-template <int D, int HSCAP /* 0: hit stack in LDS (capacity = hs_cap), else private array of HSCAP */, bool SCENE_IN_LDS>
-__global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap,
-                                                            EuDevCamera cam, EuDevFrame fr, EuDevCounters *counters,
-                                                            uint32_t *__restrict__ rgba, double *__restrict__ hit_t,
-                                                            double *__restrict__ point_rgb /* single-pixel mode: un-quantised Rgb<F> */) {
-    extern __shared__ uint64_t lds_dyn[];
-    const uint64_t *base = scene_g;
-    uint32_t lds_words = 0;
-    if (SCENE_IN_LDS) {
-        for (uint32_t i = threadIdx.x; i < scene_words; i += blockDim.x) lds_dyn[i] = scene_g[i];
-        __syncthreads();
-        base = lds_dyn;
-        lds_words = scene_words;
-    }
-    EuScene S;
-    S.init(base);
-
-    typename std::conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
-    if constexpr (HSCAP == 0) {
-        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double *hs_t = (double *)(lds_dyn + lds_words);
-        uint32_t *hs_c = (uint32_t *)(hs_t + (EU_BLOCK / 64) * hs_cap * 64);
-        HS.t = hs_t + wave * hs_cap * 64 + lane;
-        HS.c = hs_c + wave * hs_cap * 64 + lane;
-        HS.cap = hs_cap;
-    }
-    FrameStack<D> FS;
-    LaneCounters cnt = {0, 0, 0, 0};
-
-    const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;
-    const uint32_t rows = fr.local_rows;
-
-    /* lane state */
-    bool active = false;
-    uint32_t px_x = 0, px_y = 0, out_idx = 0;
-    double o[D], d[D];
-    int ent = 0;
-    uint32_t depth = 0, fsp = 0;
-    bool primary = false;
-    double first_hit = -1.0;
-
-    for (;;) {
-        /* ---- refill: idle lanes pull the next pixel (wave-aggregated atomic) ---- */
-        bool exhausted = false;
-        while (!active && !exhausted) {
-            const unsigned long long mask = __ballot(1);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            unsigned long long basei = 0;
-            if (rank == 0) basei = atomicAdd(&counters->next_item, (unsigned long long)__popcll(mask));
-            basei = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(basei >> 32)) << 32) |
-                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)basei);
-            const unsigned long long item = basei + rank;
-            if (item >= total_items) { exhausted = true; break; }
-            uint32_t ry;
-            if (fr.single_pixel) {   /* Environment::trace_screen_point: exactly one item */
-                if (item != 0) continue;
-                px_x = fr.single_x; px_y = fr.single_y; ry = 0; out_idx = 0;
-            } else {
-                const uint32_t tile = (uint32_t)(item >> 6), within = (uint32_t)(item & 63);
-                px_x = (tile % fr.tiles_x) * 8 + (within & 7);
-                ry = (tile / fr.tiles_x) * 8 + (within >> 3);
-                if (px_x >= fr.width || ry >= rows) continue;
-                if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
-                    const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
-                    px_y = fr.row_begin + gstrip * 8 + (ry & 7);
-                    if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
-                        rgba[ry * fr.width + px_x] = 0u;
-                        if (hit_t) hit_t[ry * fr.width + px_x] = -1.0;
-                        continue;
-                    }
-                } else px_y = fr.row_begin + ry;
-                out_idx = ry * fr.width + px_x;
-            }
-
-            /* Environment::render's cross-hair (universe/mod.rs:321-333) */
-            const uint32_t hw = fr.width / 2, hh = fr.height / 2;
-            if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
-                rgba[out_idx] = 0xff0000ffu;
-                if (hit_t) hit_t[out_idx] = -1.0;
-                if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
-                continue;
-            }
-            /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
-            const int sw = (int)fr.width, sh = (int)fr.height;
-            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
-            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
-            double dl[D];
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                const double center = cam.location[i] + cam.forward[i] * cam.dist;
-                const double p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
-                dl[i] = p - cam.location[i];
-                o[i] = cam.location[i];
-            }
-            vnormalize<D>(dl, d);
-            /* trace_unknown (universe/mod.rs:253-271) */
-            ent = material_at<D>(S, o);
-            if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
-                const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
-                rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-                if (hit_t) hit_t[out_idx] = -1.0;
-                if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
-                continue;
-            }
-            material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
-            depth = cam.max_depth;
-            fsp = 0;
-            primary = true;
-            first_hit = -1.0;
-            active = true;
-        }
-        if (!active) break;   /* no work left for this lane */
-
-        /* ---- TRACE one segment: Universe::trace (universe/mod.rs:149-184) ---- */
-        Rgba ret = {0.0, 0.0, 0.0, 0.0};
-        bool returning = false;
-        {
-            bool have = false;
-            double best_t = 0.0;
-            uint32_t best_code = 0, best_ent = 0;
-            if (depth > 0) {
-                cnt.rays++;
-                /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
-                for (uint32_t e = 0; e < S.n_entities; e++) {
-                    const EuFlatEntity *E = S.entity(e);
-                    if (E->surface < 0) continue;
-                    double t = 0.0; uint32_t code = 0;
-                    const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
-                    if (n == 0) continue;
-                    if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
-                }
-            }
-            if (primary) { first_hit = have ? best_t : -1.0; primary = false; }
-            if (have) {
-                /* ComposableSurface::get_color (surface.rs:62-162) */
-                HitCtx<D> c;
-#pragma unroll
-                for (int i = 0; i < D; i++) { c.loc[i] = o[i] + d[i] * best_t; c.dir[i] = d[i]; }
-                hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
-                c.exiting = angle_between<D>(c.dir, c.normal) < EU_FRAC_PI_2_C;      /* universe/mod.rs:118-125 */
-#pragma unroll
-                for (int i = 0; i < D; i++) c.nc[i] = c.exiting ? -c.normal[i] : c.normal[i];
-                const EuFlatEntity *HE = S.entity(best_ent);
-                const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
-                double ratio = reflection_ratio<D>(F, c);
-                ratio = rust_max(rust_min(ratio, 1.0), 0.0);
-
-                bool have_inter = false, need_trans = false;
-                Rgba inter = {0.0, 0.0, 0.0, 0.0};
-                uint32_t spx = 0;
-                double t_o[D], t_d[D];
-                int dest = -1;
-                if (!(ratio >= 1.0)) {                                              /* get_intersection_color */
-                    const Rgba sc = surface_color<D>(S, F, c, fr.time_s, cnt);
-                    spx = to_pixel4(sc, cnt);
-                    if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
-                    else {
-                        threshold_direction<D>(F, c, t_d);
-#pragma unroll
-                        for (int i = 0; i < D; i++) t_o[i] = c.loc[i] + -c.nc[i] * EU_EPS * 128.0;
-                        dest = c.exiting ? material_at<D>(S, t_o) : (int)best_ent;
-                        if (dest >= 0) {
-                            material_apply<D>(S, S.entity((uint32_t)ent)->material, t_d, true);
-                            material_apply<D>(S, S.entity((uint32_t)dest)->material, t_d, false);
-                            need_trans = true;
-                        }
-                    }
-                }
-                const bool need_refl = !(ratio <= 0.0);                              /* get_reflection_color */
-                double r_o[D], r_d[D];
-                if (need_refl) {
-                    const double dn = vdot<D>(c.dir, c.nc);
-#pragma unroll
-                    for (int i = 0; i < D; i++) {
-                        r_d[i] = c.nc[i] * -2.0 * dn + c.dir[i];                     /* surface.rs:246-256 */
-                        r_o[i] = c.loc[i] + c.nc[i] * EU_EPS * 128.0;
-                    }
-                }
-                const uint32_t child_depth = depth - 1;
-                if (need_trans) {
-                    if (need_refl) {
-                        FS.meta[fsp] = FR_TRANS_THEN_REFL | (child_depth << 8) | ((uint32_t)ent << 16);
-                        FS.ratio[fsp] = ratio;
-#pragma unroll
-                        for (int i = 0; i < D; i++) { FS.data[fsp][i] = r_o[i]; FS.data[fsp][D + i] = r_d[i]; }
-                    } else {
-                        FS.meta[fsp] = FR_OVER;
-                    }
-                    FS.px[fsp] = spx;
-                    fsp++;
-#pragma unroll
-                    for (int i = 0; i < D; i++) { o[i] = t_o[i]; d[i] = t_d[i]; }
-                    ent = dest;
-                    depth = child_depth;
-                } else if (need_refl) {
-                    if (have_inter) {
-                        FS.meta[fsp] = FR_COMBINE;
-                        FS.ratio[fsp] = ratio;
-                        FS.data[fsp][0] = inter.r; FS.data[fsp][1] = inter.g; FS.data[fsp][2] = inter.b; FS.data[fsp][3] = inter.a;
-                        fsp++;
-                    }   /* else: the reflection colour is the result (surface.rs:153-154): tail call */
-#pragma unroll
-                    for (int i = 0; i < D; i++) { o[i] = r_o[i]; d[i] = r_d[i]; }
-                    depth = child_depth;
-                } else {
-                    if (!have_inter) cnt.errors++;            /* the reference panics here (surface.rs:154) */
-                    ret = inter;
-                    returning = true;
-                }
-            } else {
-                /* background().get_color(&direction.to_point()) (universe/mod.rs:183) */
-                cnt.bg++;
-                double pt[D];
-#pragma unroll
-                for (int i = 0; i < D; i++) pt[i] = 0.0 + d[i];
-                ret = mapped_get_color(S, S.background, pt, cnt);
-                returning = true;
-            }
-        }
-
-        /* ---- RETURN through pending frames ---- */
-        while (returning) {
-            if (fsp == 0) {
-                /* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-                const Rgba white = {1.0, 1.0, 1.0, 1.0};
-                const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(ret), into_premultiplied(white)));
-                const uint32_t idx = out_idx;
-                rgba[idx] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
-                if (hit_t) hit_t[idx] = first_hit;
-                if (point_rgb) { point_rgb[0] = out.r; point_rgb[1] = out.g; point_rgb[2] = out.b; }
-                active = false;
-                break;
-            }
-            fsp--;
-            const uint32_t meta = FS.meta[fsp];
-            const uint32_t kind = meta & 0xff;
-            if (kind == FR_COMBINE) {                                               /* surface.rs:159-161 */
-                const Rgba inter = {FS.data[fsp][0], FS.data[fsp][1], FS.data[fsp][2], FS.data[fsp][3]};
-                ret = combine_palette_color(ret, inter, FS.ratio[fsp]);
-            } else {
-                /* surface_palette.over(transition_palette), both re-quantised to u8 (surface.rs:104-114) */
-                const uint32_t tpx = to_pixel4(ret, cnt);
-                const Rgba inter = blend_rgba(EU_BL_OVER, new_u8(FS.px[fsp]), new_u8(tpx));
-                if (kind == FR_OVER) ret = inter;
-                else {                                                              /* now the reflection child */
-#pragma unroll
-                    for (int i = 0; i < D; i++) { o[i] = FS.data[fsp][i]; d[i] = FS.data[fsp][D + i]; }
-                    ent = (int)(meta >> 16);
-                    depth = (meta >> 8) & 0xff;
-                    FS.meta[fsp] = FR_COMBINE;
-                    FS.data[fsp][0] = inter.r; FS.data[fsp][1] = inter.g; FS.data[fsp][2] = inter.b; FS.data[fsp][3] = inter.a;
-                    fsp++;
-                    returning = false;
-                }
-            }
-        }
-    }
-
-    /* ---- counters: wave reduction, one atomic per wave and counter ---- */
-    unsigned long long v0 = cnt.rays, v1 = cnt.bg, v2 = cnt.nan_px, v3 = cnt.errors;
-    for (int off = 32; off > 0; off >>= 1) {
-        v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (v0) atomicAdd(&counters->rays, v0);
-        if (v1) atomicAdd(&counters->bg_samples, v1);
-        if (v2) atomicAdd(&counters->nan_pixels, v2);
-        if (v3) atomicAdd(&counters->errors, v3);
-    }
-}
+#include "trace_megakernel.h"
+#include "trace_wavefront.h"
 
 /* RGBA8 -> packed RGB8 (RawImage2d U8U8U8, universe/mod.rs:351-356): 4 pixels (16 B in, 12 B out) per thread */
 __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *__restrict__ rgb, size_t pixels) {
@@ -358,6 +87,12 @@ struct eu_renderer {
     bool have_timing = false;
     int num_cus = 0;
     bool scene_in_lds = true;
+    /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
+    bool use_wavefront = true;
+    EuWfBuffers wf{};
+    size_t wf_pixels = 0;
+    double wf_ray_factor = 4.0, wf_node_factor = 16.0;
+    std::vector<void *> wf_allocs;
     std::string err;
 };
 
@@ -414,6 +149,10 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         }
         r->scene_words = (uint32_t)blob.size();
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
+        if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
+        if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
+        if (const char *k = getenv("EU_WF_NODE_FACTOR")) r->wf_node_factor = atof(k);
+        if (!r->scene_in_lds || h.hit_cap > 64) r->use_wavefront = false;   /* huge scenes: megakernel with the hit stack in scratch */
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
@@ -432,6 +171,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     for (void *p : r->d_textures) (void)hipFree(p);
+    for (void *p : r->wf_allocs) (void)hipFree(p);
     if (r->d_scene) (void)hipFree(r->d_scene);
     if (r->d_counters) (void)hipFree(r->d_counters);
     if (r->d_rgba) (void)hipFree(r->d_rgba);
@@ -466,7 +206,7 @@ static int make_dev_camera(const eu_camera *cam, const eu_frame *f, EuDevCamera 
 template <int D, int HSCAP, bool LDS>
 static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
     auto kern = eu_trace_kernel<D, HSCAP, LDS>;
-    const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap < 4 ? 4u : ((r->hit_cap + 3u) & ~3u));
+    const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u));
     size_t lds_bytes = LDS ? (size_t)r->scene_words * 8 : 0;
     if (HSCAP == 0) lds_bytes += (size_t)(EU_BLOCK / 64) * hs_cap * 64 * 12;
     int blocks_per_cu = 0;
@@ -480,6 +220,83 @@ static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCa
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(EU_BLOCK), lds_bytes, stream, r->d_scene, r->scene_words, hs_cap, dc, df, r->d_counters, rgba, hit_t, point);
     return hipGetLastError();
+}
+
+
+/* ------------------------------------------------------------------ wavefront pipeline (trace_wavefront.h) */
+static int wf_ensure(eu_renderer *r, size_t pixels) {
+    if (pixels <= r->wf_pixels) return EU_OK;
+    for (void *p : r->wf_allocs) (void)hipFree(p);
+    r->wf_allocs.clear();
+    r->wf_pixels = 0;
+    const int D = r->dim;
+    EuWfBuffers &B = r->wf;
+    memset(&B, 0, sizeof B);
+    const size_t ray_cap = (size_t)((double)pixels * r->wf_ray_factor) + 65536;
+    const size_t node_cap = pixels + (size_t)((double)pixels * r->wf_node_factor) + 65536;
+    if (ray_cap > 0xfffffff0ull || node_cap > 0xfffffff0ull) { r->err = "frame too large for 32-bit queue indices; render it in row tiles"; return EU_ERR_CAPACITY; }
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(p, bytes));
+        r->wf_allocs.push_back(*p);
+        return EU_OK;
+    };
+    int rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = alloc((void **)&B.ray_od[k], ray_cap * 2 * D * sizeof(double)))) return rc;
+        if ((rc = alloc((void **)&B.ray_parent[k], ray_cap * 4))) return rc;
+        if ((rc = alloc((void **)&B.ray_aux[k], ray_cap * 4))) return rc;
+    }
+    if ((rc = alloc((void **)&B.hit_t, ray_cap * 8))) return rc;
+    if ((rc = alloc((void **)&B.hit_code, ray_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.hit_ent, ray_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.node_child, node_cap * 8 * sizeof(double)))) return rc;
+    if ((rc = alloc((void **)&B.node_ratio, node_cap * 8))) return rc;
+    if ((rc = alloc((void **)&B.node_px, node_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.node_meta, node_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.node_parent, node_cap * 4))) return rc;
+    B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
+    r->wf_pixels = pixels;
+    return EU_OK;
+}
+
+template <class K> static int wf_grid(eu_renderer *r, K kern, size_t lds_bytes, unsigned &grid) {
+    int blocks_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, EU_WF_BLOCK, lds_bytes));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    grid = (unsigned)(r->num_cus * blocks_per_cu);
+    return EU_OK;
+}
+
+template <int D>
+static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
+    const size_t pixels = (size_t)df.local_rows * df.width;
+    int rc = wf_ensure(r, df.single_pixel ? 64 : pixels);
+    if (rc != EU_OK) return rc;
+    EuWfBuffers B = r->wf;
+    B.npix = df.single_pixel ? 1u : (uint32_t)pixels;
+    const size_t scene_bytes = (size_t)r->scene_words * 8;
+    const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    const size_t isect_lds = scene_bytes + (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;
+    unsigned g_gen, g_isect, g_shade, g_res;
+    if ((rc = wf_grid(r, eu_wf_gen_kernel<D>, scene_bytes, g_gen))) return rc;
+    if ((rc = wf_grid(r, eu_wf_intersect_kernel<D>, isect_lds, g_isect))) return rc;
+    if ((rc = wf_grid(r, eu_wf_shade_kernel<D>, scene_bytes, g_shade))) return rc;
+    if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
+    const unsigned long long items = (unsigned long long)df.n_tiles * 64ull;
+    unsigned gg = (unsigned)((items + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
+    if (gg < g_gen) g_gen = gg ? gg : 1;
+    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_gen), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
+    for (uint32_t g = 0; g < dc.max_depth; g++) {
+        hipLaunchKernelGGL(eu_wf_intersect_kernel<D>, dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
+        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_shade), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+    }
+    for (uint32_t g = dc.max_depth; g-- > 0;)
+        hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);
+    unsigned gf = (unsigned)((B.npix + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
+    if (gf > g_res * 4) gf = g_res * 4;
+    hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, r->d_counters, rgba, point);
+    HIP_TRY(hipGetLastError());
+    return EU_OK;
 }
 
 static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_frame *f, hipStream_t stream, uint32_t *rgba, double *hit_t, double *point,
@@ -510,7 +327,11 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, sizeof(EuDevCounters), stream));
     const int slot = (int)(r->launches % eu_renderer::EV_RING);
     HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
-    hipError_t e;
+    hipError_t e = hipSuccess;
+    if (r->use_wavefront) {
+        int rc = (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
+        if (rc != EU_OK) return rc;
+    } else {
     /* hit stack in LDS when the scene's static bound is small (16 entries * 12 B * 256 lanes = 48 KB per block) */
     const bool hs_lds = r->hit_cap <= 32 && r->scene_in_lds;
     if (r->dim == 3) {
@@ -521,6 +342,7 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
         if (hs_lds) e = launch_trace<4, 0, true>(r, stream, dc, df, rgba, hit_t, point);
         else if (r->scene_in_lds) e = launch_trace<4, 96, true>(r, stream, dc, df, rgba, hit_t, point);
         else e = launch_trace<4, 96, false>(r, stream, dc, df, rgba, hit_t, point);
+    }
     }
     if (e != hipSuccess) { r->err = std::string("kernel launch: ") + hipGetErrorString(e); return EU_ERR_HIP; }
     HIP_TRY(hipEventRecord(r->ev_stop[slot], stream));
@@ -561,6 +383,17 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c.rays; out->bg_samples = c.bg_samples; out->nan_pixels = c.nan_pixels; out->errors = c.errors;
+    if (c.overflow) { r->err = "wavefront queue overflow (" + std::to_string(c.overflow) + " rays dropped): raise EU_WF_RAY_FACTOR / EU_WF_NODE_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
+    return EU_OK;
+}
+
+extern "C" int eu_renderer_debug_phases(eu_renderer *r, unsigned long long out[8]) {
+    if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->last_stream));
+    EuDevCounters c;
+    HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = c.phase[i];
     return EU_OK;
 }
 
