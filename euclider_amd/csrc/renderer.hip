@@ -91,7 +91,7 @@ struct eu_renderer {
     bool use_wavefront = true;
     EuWfBuffers wf{};
     size_t wf_pixels = 0;
-    double wf_ray_factor = 4.0, wf_node_factor = 16.0;
+    double wf_ray_factor = 4.0;
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -151,7 +151,6 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
-        if (const char *k = getenv("EU_WF_NODE_FACTOR")) r->wf_node_factor = atof(k);
         if (!r->scene_in_lds || h.hit_cap > 64) r->use_wavefront = false;   /* huge scenes: megakernel with the hit stack in scratch */
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
@@ -232,9 +231,15 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     const int D = r->dim;
     EuWfBuffers &B = r->wf;
     memset(&B, 0, sizeof B);
-    const size_t ray_cap = (size_t)((double)pixels * r->wf_ray_factor) + 65536;
-    const size_t node_cap = pixels + (size_t)((double)pixels * r->wf_node_factor) + 65536;
-    if (ray_cap > 0xfffffff0ull || node_cap > 0xfffffff0ull) { r->err = "frame too large for 32-bit queue indices; render it in row tiles"; return EU_ERR_CAPACITY; }
+    /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
+    uint32_t n_seg = (uint32_t)r->num_cus * 3u;
+    if (n_seg > EU_WF_MAX_SEG) n_seg = EU_WF_MAX_SEG;
+    size_t seg_cap = ((size_t)((double)pixels * r->wf_ray_factor) + n_seg - 1) / n_seg;
+    if (seg_cap < 2048) seg_cap = 2048;        /* small frames: absorb uneven segments */
+    seg_cap = (seg_cap + 255) & ~(size_t)255;
+    const size_t ray_cap = seg_cap * n_seg;
+    const size_t node_cap = pixels + ray_cap * (EU_MAX_DEPTH + 1);
+    if (ray_cap > 0x7ffffff0ull || node_cap > 0xfffffff0ull) { r->err = "frame too large for 32-bit queue indices; render it in row tiles"; return EU_ERR_CAPACITY; }
     auto alloc = [&](void **p, size_t bytes) -> int {
         HIP_TRY(hipMalloc(p, bytes));
         r->wf_allocs.push_back(*p);
@@ -249,12 +254,16 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     if ((rc = alloc((void **)&B.hit_t, ray_cap * 8))) return rc;
     if ((rc = alloc((void **)&B.hit_code, ray_cap * 4))) return rc;
     if ((rc = alloc((void **)&B.hit_ent, ray_cap * 4))) return rc;
+    /* node ids are static: pixel roots, then generation g's queue slot q at pixels + g*ray_cap + q
+     * (only the slots that hold rays are ever touched) */
     if ((rc = alloc((void **)&B.node_child, node_cap * 8 * sizeof(double)))) return rc;
     if ((rc = alloc((void **)&B.node_ratio, node_cap * 8))) return rc;
     if ((rc = alloc((void **)&B.node_px, node_cap * 4))) return rc;
     if ((rc = alloc((void **)&B.node_meta, node_cap * 4))) return rc;
     if ((rc = alloc((void **)&B.node_parent, node_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.seg_count, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4))) return rc;
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
+    B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
     r->wf_pixels = pixels;
     return EU_OK;
 }
@@ -277,23 +286,19 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     const size_t scene_bytes = (size_t)r->scene_words * 8;
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t isect_lds = scene_bytes + (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;
-    unsigned g_gen, g_isect, g_shade, g_res;
-    if ((rc = wf_grid(r, eu_wf_gen_kernel<D>, scene_bytes, g_gen))) return rc;
+    unsigned g_isect, g_res;
     if ((rc = wf_grid(r, eu_wf_intersect_kernel<D>, isect_lds, g_isect))) return rc;
-    if ((rc = wf_grid(r, eu_wf_shade_kernel<D>, scene_bytes, g_shade))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
-    const unsigned long long items = (unsigned long long)df.n_tiles * 64ull;
-    unsigned gg = (unsigned)((items + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
-    if (gg < g_gen) g_gen = gg ? gg : 1;
-    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_gen), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
+    const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
+    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
     for (uint32_t g = 0; g < dc.max_depth; g++) {
         hipLaunchKernelGGL(eu_wf_intersect_kernel<D>, dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
-        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_shade), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
     }
     for (uint32_t g = dc.max_depth; g-- > 0;)
         hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);
     unsigned gf = (unsigned)((B.npix + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
-    if (gf > g_res * 4) gf = g_res * 4;
+    if (gf > (unsigned)r->num_cus * 16u) gf = (unsigned)r->num_cus * 16u;
     hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, r->d_counters, rgba, point);
     HIP_TRY(hipGetLastError());
     return EU_OK;
@@ -383,7 +388,7 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c.rays; out->bg_samples = c.bg_samples; out->nan_pixels = c.nan_pixels; out->errors = c.errors;
-    if (c.overflow) { r->err = "wavefront queue overflow (" + std::to_string(c.overflow) + " rays dropped): raise EU_WF_RAY_FACTOR / EU_WF_NODE_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
+    if (c.overflow) { r->err = "wavefront queue overflow (" + std::to_string(c.overflow) + " rays dropped): raise EU_WF_RAY_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
     return EU_OK;
 }
 

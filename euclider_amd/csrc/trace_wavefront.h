@@ -18,7 +18,11 @@
  *   final kernel          per pixel: fg.over(white), to_pixel (universe/mod.rs:263-269,342) -> RGBA8
  *
  * Everything a ray needs between kernels lives in HBM as struct-of-arrays queues (coalesced), sized
- * for the 288 GB part; every kernel is small enough for the register allocator to reach several
+ * for the 288 GB part.  A queue is cut into one SEGMENT per producer workgroup: a workgroup appends
+ * its children to its own segment through an LDS counter (no global atomics: a single hot counter
+ * saturates at ~88 appends/us on this chip and was the first bottleneck), publishes the segment
+ * length when it ends, and the next kernel's workgroups walk whole segments.  Queue slot ids are
+ * static (segment * segment_capacity + offset), so tree-node ids need no prefix sums either; every kernel is small enough for the register allocator to reach several
  * waves per SIMD, and queues keep all 64 lanes busy whatever the per-pixel ray count is.  The order in
  * which rays are processed does not matter: every step is a pure function, so the result is
  * bit-identical to the depth-first recursion.
@@ -45,10 +49,10 @@ struct EuWfBuffers {
     uint32_t *node_px;
     uint32_t *node_meta;        /* kind | slot-in-parent << 8 */
     uint32_t *node_parent;
+    uint32_t *seg_count;        /* [EU_MAX_DEPTH + 1][n_seg] rays in each segment of each generation's queue */
     uint32_t ray_cap, node_cap, npix, pad;
+    uint32_t n_seg, seg_cap;    /* ray_cap = n_seg * seg_cap; node id of queue slot q of generation g = npix + g * ray_cap + q */
 };
-
-/* generation bookkeeping lives in EuDevCounters::gen_count[] (device memory, zeroed per frame) */
 
 EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) {
     unsigned long long v0 = cnt.rays, v1 = cnt.bg, v2 = cnt.nan_px, v3 = cnt.errors;
@@ -63,21 +67,54 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
     }
 }
 
-/* wave-aggregated append: returns this lane's slot in the queue (call from divergent code is fine) */
-EU_DEV unsigned long long wf_append(unsigned long long *counter) {
-    const unsigned long long mask = __ballot(1);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    unsigned long long base = 0;
-    if (rank == 0) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-           (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
-    return base + rank;
+/* append to this workgroup's output segment: wave-aggregated add on an LDS counter */
+EU_DEV uint32_t wf_append_local(uint32_t *lds_counter, uint32_t n /* 0..2 slots wanted by this lane */, uint32_t &second) {
+    const unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
+    const uint32_t lo = (uint32_t)m1, hi = (uint32_t)(m1 >> 32), lo2 = (uint32_t)m2, hi2 = (uint32_t)(m2 >> 32);
+    const uint32_t rank1 = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    const uint32_t rank2 = __builtin_amdgcn_mbcnt_hi(hi2, __builtin_amdgcn_mbcnt_lo(lo2, 0u));
+    const uint32_t total = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(lds_counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    /* first slots of all lanes, then second slots */
+    second = base + (uint32_t)__popcll(m1) + rank2;
+    return base + rank1;
 }
 
 EU_DEV const uint64_t *wf_stage_scene(const uint64_t *scene_g, uint32_t scene_words, uint64_t *lds) {
     for (uint32_t i = threadIdx.x; i < scene_words; i += blockDim.x) lds[i] = scene_g[i];
     __syncthreads();
     return lds;
+}
+
+/* Balanced consumption of a segmented queue: every workgroup scans the (<= 1024) segment lengths of
+ * the generation into LDS; the rays then form one virtual index space that is dealt out grid-stride,
+ * and a lane maps its virtual index back to (segment, offset) with a binary search in LDS. */
+#define EU_WF_MAX_SEG 1024
+EU_DEV uint32_t wf_build_prefix(const uint32_t *seg_count, uint32_t n_seg, uint32_t *pref /* LDS, n_seg + 1 words */, uint32_t *wave_tot /* LDS, 4 words */) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = t * 4 + k; v[k] = idx < n_seg ? seg_count[idx] : 0u; s += v[k]; }
+    uint32_t inc = s;                                  /* inclusive scan inside the wave */
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+    uint32_t run = base + inc - s;                     /* exclusive prefix of this thread's first element */
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = t * 4 + k; if (idx < n_seg) pref[idx] = run; run += v[k]; }
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (t == 0) pref[n_seg] = total;
+    __syncthreads();
+    return total;
+}
+EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_cap, uint32_t v) {
+    uint32_t lo = 0, hi = n_seg;                       /* largest seg with pref[seg] <= v */
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= v) lo = mid; else hi = mid; }
+    return lo * seg_cap + (v - pref[lo]);
 }
 
 EU_DEV void wf_deliver(const EuWfBuffers &B, uint32_t parent, uint32_t slot, const Rgba &c) {
@@ -94,86 +131,114 @@ template <int D> EU_DEV Rgba wf_background(const EuScene &S, const double *d, La
     return mapped_get_color(S, S.background, pt, cnt);
 }
 
+/* ------------------------------------------------------------------ queue helpers */
+struct WfRay { uint32_t q; };
+
+template <int D> EU_DEV void wf_store_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, const double *o, const double *d, uint32_t parent, uint32_t aux) {
+#pragma unroll
+    for (int k = 0; k < D; k++) { B.ray_od[buf][(size_t)k * B.ray_cap + q] = o[k]; B.ray_od[buf][(size_t)(D + k) * B.ray_cap + q] = d[k]; }
+    B.ray_parent[buf][q] = parent;
+    B.ray_aux[buf][q] = aux;
+}
+
 /* ------------------------------------------------------------------ primary rays */
 template <int D>
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,
                                                                 EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba,
                                                                 double *__restrict__ hit_t, double *__restrict__ point_rgb) {
     extern __shared__ uint64_t lds_dyn[];
+    __shared__ uint32_t seg_fill;
+    if (threadIdx.x == 0) seg_fill = 0;
     EuScene S;
     S.init(wf_stage_scene(scene_g, scene_words, lds_dyn));
+    LaneCounters cnt = {0, 0, 0, 0};
     const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;
     const uint32_t rows = fr.local_rows;
-    for (unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; item < total_items;
-         item += (unsigned long long)gridDim.x * blockDim.x) {
-        uint32_t px_x, px_y, ry, out_idx;
-        if (fr.single_pixel) {      /* Environment::trace_screen_point: exactly one item */
-            if (item != 0) continue;
-            px_x = fr.single_x; px_y = fr.single_y; ry = 0; out_idx = 0;
-        } else {
-            const uint32_t tile = (uint32_t)(item >> 6), within = (uint32_t)(item & 63);   /* 8x8 pixel tiles: coherent waves */
-            px_x = (tile % fr.tiles_x) * 8 + (within & 7);
-            ry = (tile / fr.tiles_x) * 8 + (within >> 3);
-            if (px_x >= fr.width || ry >= rows) continue;
-            out_idx = ry * fr.width + px_x;
-            if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
-                const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
-                px_y = fr.row_begin + gstrip * 8 + (ry & 7);
-                if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
-                    rgba[out_idx] = 0u;
-                    if (hit_t) hit_t[out_idx] = -1.0;
-                    B.node_meta[out_idx] = WF_NONE;
-                    continue;
-                }
-            } else px_y = fr.row_begin + ry;
-        }
-        B.node_meta[out_idx] = WF_NONE;
-        if (hit_t) hit_t[out_idx] = -1.0;
-        /* Environment::render's cross-hair (universe/mod.rs:321-333) */
-        const uint32_t hw = fr.width / 2, hh = fr.height / 2;
-        if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
-            rgba[out_idx] = 0xff0000ffu;
-            if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
-            continue;
-        }
-        /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
-        const int sw = (int)fr.width, sh = (int)fr.height;
-        const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
-        const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
-        double o[D], d[D], dl[D];
+    const uint32_t seg_base = blockIdx.x * B.seg_cap;
+    /* every workgroup takes an equal, contiguous share of the pixel tiles (whole 64-pixel tiles), so that
+     * all queue segments fill evenly; whole iterations for every lane (the block-wide append sees all waves) */
+    unsigned long long chunk = (total_items + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + 63ull) & ~63ull;
+    const unsigned long long chunk_begin = (unsigned long long)blockIdx.x * chunk;
+    const unsigned long long iters = (chunk + blockDim.x - 1) / blockDim.x;
+    for (unsigned long long it = 0; it < iters; it++) {
+        const unsigned long long local = it * blockDim.x + threadIdx.x;
+        const unsigned long long item = local < chunk ? chunk_begin + local : total_items;
+        bool have_ray = false;
+        double o[D], d[D];
+        uint32_t out_idx = 0, ent_u = 0;
+        do {
+            if (item >= total_items) break;
+            uint32_t px_x, px_y, ry;
+            if (fr.single_pixel) {      /* Environment::trace_screen_point: exactly one item */
+                if (item != 0) break;
+                px_x = fr.single_x; px_y = fr.single_y; ry = 0; out_idx = 0;
+            } else {
+                const uint32_t tile = (uint32_t)(item >> 6), within = (uint32_t)(item & 63);   /* 8x8 pixel tiles: coherent waves */
+                px_x = (tile % fr.tiles_x) * 8 + (within & 7);
+                ry = (tile / fr.tiles_x) * 8 + (within >> 3);
+                if (px_x >= fr.width || ry >= rows) break;
+                out_idx = ry * fr.width + px_x;
+                if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
+                    const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
+                    px_y = fr.row_begin + gstrip * 8 + (ry & 7);
+                    if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
+                        rgba[out_idx] = 0u;
+                        if (hit_t) hit_t[out_idx] = -1.0;
+                        B.node_meta[out_idx] = WF_NONE;
+                        break;
+                    }
+                } else px_y = fr.row_begin + ry;
+            }
+            B.node_meta[out_idx] = WF_NONE;
+            if (hit_t) hit_t[out_idx] = -1.0;
+            /* Environment::render's cross-hair (universe/mod.rs:321-333) */
+            const uint32_t hw = fr.width / 2, hh = fr.height / 2;
+            if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
+                rgba[out_idx] = 0xff0000ffu;
+                if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
+                break;
+            }
+            /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
+            const int sw = (int)fr.width, sh = (int)fr.height;
+            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
+            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
+            double dl[D];
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const double center = cam.location[i] + cam.forward[i] * cam.dist;
-            const double p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
-            dl[i] = p - cam.location[i];
-            o[i] = cam.location[i];
+            for (int i = 0; i < D; i++) {
+                const double center = cam.location[i] + cam.forward[i] * cam.dist;
+                const double p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
+                dl[i] = p - cam.location[i];
+                o[i] = cam.location[i];
+            }
+            vnormalize<D>(dl, d);
+            /* trace_unknown (universe/mod.rs:253-271) */
+            const int ent = material_at<D>(S, o);
+            if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
+                const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
+                rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
+                if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
+                break;
+            }
+            material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
+            B.node_meta[out_idx] = WF_ROOT;
+            if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
+                wf_deliver(B, out_idx, 0, wf_background<D>(S, d, cnt));
+                break;
+            }
+            ent_u = (uint32_t)ent;
+            have_ray = true;
+        } while (false);
+        uint32_t second;
+        const uint32_t pos = wf_append_local(&seg_fill, have_ray ? 1u : 0u, second);
+        if (have_ray) {
+            if (pos >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
+            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx, ent_u);
         }
-        vnormalize<D>(dl, d);
-        /* trace_unknown (universe/mod.rs:253-271) */
-        const int ent = material_at<D>(S, o);
-        if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
-            const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
-            rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-            if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
-            continue;
-        }
-        material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
-        B.node_meta[out_idx] = WF_ROOT;
-        if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
-            LaneCounters cnt = {0, 0, 0, 0};
-            const Rgba c = wf_background<D>(S, d, cnt);
-            wf_deliver(B, out_idx, 0, c);
-            atomicAdd(&counters->bg_samples, 1ull);
-            if (cnt.errors) atomicAdd(&counters->errors, (unsigned long long)cnt.errors);
-            continue;
-        }
-        const unsigned long long pos = wf_append(&counters->gen_count[0]);
-        if (pos >= B.ray_cap) { atomicAdd(&counters->overflow, 1ull); continue; }
-#pragma unroll
-        for (int i = 0; i < D; i++) { B.ray_od[0][(size_t)i * B.ray_cap + pos] = o[i]; B.ray_od[0][(size_t)(D + i) * B.ray_cap + pos] = d[i]; }
-        B.ray_parent[0][pos] = out_idx;
-        B.ray_aux[0][pos] = (uint32_t)ent;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) B.seg_count[blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
+    wf_flush_counters(counters, cnt);
 }
 
 /* ------------------------------------------------------------------ trace_closest */
@@ -193,146 +258,180 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
         HS.cap = hs_cap;
     }
     LaneCounters cnt = {0, 0, 0, 0};
-    const unsigned long long count = counters->gen_count[gen] < B.ray_cap ? counters->gen_count[gen] : B.ray_cap;
     const uint32_t in = gen & 1u;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
-        double o[D], d[D];
+    __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    {
+        for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+            const uint32_t i = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+            double o[D], d[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
-        cnt.rays++;
-        /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
-        bool have = false;
-        double best_t = 0.0;
-        uint32_t best_code = 0, best_ent = 0xffffffffu;
-        for (uint32_t e = 0; e < S.n_entities; e++) {
-            const EuFlatEntity *E = S.entity(e);
-            if (E->surface < 0) continue;
-            double t = 0.0; uint32_t code = 0;
-            const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
-            if (n == 0) continue;
-            if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
+            for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
+            cnt.rays++;
+            /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
+            bool have = false;
+            double best_t = 0.0;
+            uint32_t best_code = 0, best_ent = 0xffffffffu;
+            for (uint32_t e = 0; e < S.n_entities; e++) {
+                const EuFlatEntity *E = S.entity(e);
+                if (E->surface < 0) continue;
+                double t = 0.0; uint32_t code = 0;
+                const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                if (n == 0) continue;
+                if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
+            }
+            B.hit_t[i] = best_t;
+            B.hit_code[i] = best_code;
+            B.hit_ent[i] = best_ent;
+            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -1.0;
         }
-        B.hit_t[i] = best_t;
-        B.hit_code[i] = best_code;
-        B.hit_ent[i] = best_ent;
-        if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -1.0;
     }
     wf_flush_counters(counters, cnt);
 }
 
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
 template <int D>
-EU_DEV void wf_spawn(const EuScene &S, const EuWfBuffers &B, EuDevCounters *counters, uint32_t gen, uint32_t child_depth,
-                     const double *o, const double *d, uint32_t ent, uint32_t parent, uint32_t slot, LaneCounters &cnt) {
-    if (child_depth == 0) {     /* trace() with max_depth 0: background only (universe/mod.rs:157,183) */
-        wf_deliver(B, parent, slot, wf_background<D>(S, d, cnt));
-        return;
-    }
-    const unsigned long long pos = wf_append(&counters->gen_count[gen + 1]);
-    if (pos >= B.ray_cap) { atomicAdd(&counters->overflow, 1ull); return; }
-    const uint32_t out = (gen + 1) & 1u;
-#pragma unroll
-    for (int k = 0; k < D; k++) { B.ray_od[out][(size_t)k * B.ray_cap + pos] = o[k]; B.ray_od[out][(size_t)(D + k) * B.ray_cap + pos] = d[k]; }
-    B.ray_parent[out][pos] = parent;
-    B.ray_aux[out][pos] = ent | (slot << 16);
-}
-
-template <int D>
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
                                                                   EuWfBuffers B, EuDevCounters *counters) {
     extern __shared__ uint64_t lds_dyn[];
+    __shared__ uint32_t seg_fill;
+    if (threadIdx.x == 0) seg_fill = 0;
     EuScene S;
     S.init(wf_stage_scene(scene_g, scene_words, lds_dyn));
     LaneCounters cnt = {0, 0, 0, 0};
-    const unsigned long long count = counters->gen_count[gen] < B.ray_cap ? counters->gen_count[gen] : B.ray_cap;
-    unsigned long long gen_base = B.npix;
-    for (uint32_t h = 0; h < gen; h++) gen_base += counters->gen_count[h] < B.ray_cap ? counters->gen_count[h] : B.ray_cap;
-    const uint32_t in = gen & 1u;
+    const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long nid64 = gen_base + i;
-        const uint32_t parent = B.ray_parent[in][i];
-        const uint32_t aux = B.ray_aux[in][i];
-        const uint32_t ent = aux & 0xffffu, slot = (aux >> 16) & 1u;
-        double o[D], d[D];
+    const uint32_t out_base = blockIdx.x * B.seg_cap;
+    const uint32_t node_base = B.npix + gen * B.ray_cap;       /* node id of queue slot q: node_base + q */
+    __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    {
+        const uint32_t stride = gridDim.x * blockDim.x;
+        const uint32_t iters = (total + stride - 1) / stride;             /* whole iterations: block-wide append below */
+        for (uint32_t it = 0; it < iters; it++) {
+            const uint32_t v = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+            const bool live = v < total;
+            const uint32_t i = live ? wf_map_index(pref, B.n_seg, B.seg_cap, v) : 0u;
+            const uint32_t nid = node_base + i;
+            /* children of this ray: 0 = transmission, 1 = reflection */
+            uint32_t n_child = 0;
+            double c_o[2][D], c_d[2][D];
+            uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_slot[2] = {0, 0};
+            if (live) {
+                const uint32_t parent = B.ray_parent[in][i];
+                const uint32_t aux = B.ray_aux[in][i];
+                const uint32_t ent = aux & 0xffffu, slot = (aux >> 16) & 1u;
+                double o[D], d[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
-        const uint32_t hit_ent = B.hit_ent[i];
-        if (nid64 >= B.node_cap) { atomicAdd(&counters->overflow, 1ull); continue; }
-        const uint32_t nid = (uint32_t)nid64;
-        uint32_t node_kind = WF_NONE;
-        if (hit_ent == 0xffffffffu) {
-            wf_deliver(B, parent, slot, wf_background<D>(S, d, cnt));
-        } else {
-            const double best_t = B.hit_t[i];
-            const uint32_t best_code = B.hit_code[i];
-            HitCtx<D> c;
+                for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
+                const uint32_t hit_ent = B.hit_ent[i];
+                uint32_t node_kind = WF_NONE;
+                if (hit_ent == 0xffffffffu) {
+                    /* nothing hit: the background colour goes to the parent; handled as a depth-0 "child" below */
 #pragma unroll
-            for (int k = 0; k < D; k++) { c.loc[k] = o[k] + d[k] * best_t; c.dir[k] = d[k]; }
-            hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
-            c.exiting = angle_between<D>(c.dir, c.normal) < EU_FRAC_PI_2_C;      /* universe/mod.rs:118-125 */
+                    for (int k = 0; k < D; k++) { c_o[0][k] = o[k]; c_d[0][k] = d[k]; }
+                    c_parent[0] = parent; c_slot[0] = slot | 2u;       /* bit 1: background only */
+                    n_child = 1;
+                } else {
+                    const double best_t = B.hit_t[i];
+                    const uint32_t best_code = B.hit_code[i];
+                    HitCtx<D> c;
 #pragma unroll
-            for (int k = 0; k < D; k++) c.nc[k] = c.exiting ? -c.normal[k] : c.normal[k];
-            const EuFlatEntity *HE = S.entity(hit_ent);
-            const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
-            double ratio = reflection_ratio<D>(F, c);
-            ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
+                    for (int k = 0; k < D; k++) { c.loc[k] = o[k] + d[k] * best_t; c.dir[k] = d[k]; }
+                    hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
+                    c.exiting = angle_between<D>(c.dir, c.normal) < EU_FRAC_PI_2_C;      /* universe/mod.rs:118-125 */
+#pragma unroll
+                    for (int k = 0; k < D; k++) c.nc[k] = c.exiting ? -c.normal[k] : c.normal[k];
+                    const EuFlatEntity *HE = S.entity(hit_ent);
+                    const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
+                    double ratio = reflection_ratio<D>(F, c);
+                    ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
 
-            bool have_inter = false, need_trans = false;
-            Rgba inter = {0.0, 0.0, 0.0, 0.0};
-            uint32_t spx = 0;
-            double t_o[D], t_d[D];
-            int dest = -1;
-            if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
-                const Rgba sc = surface_color<D>(S, F, c, time_s, cnt);
-                spx = to_pixel4(sc, cnt);
-                if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
-                else {
-                    threshold_direction<D>(F, c, t_d);
+                    bool have_inter = false, need_trans = false;
+                    Rgba inter = {0.0, 0.0, 0.0, 0.0};
+                    uint32_t spx = 0;
+                    int dest = -1;
+                    if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
+                        const Rgba sc = surface_color<D>(S, F, c, time_s, cnt);
+                        spx = to_pixel4(sc, cnt);
+                        if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
+                        else {
+                            threshold_direction<D>(F, c, c_d[0]);
 #pragma unroll
-                    for (int k = 0; k < D; k++) t_o[k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
-                    dest = c.exiting ? material_at<D>(S, t_o) : (int)hit_ent;
-                    if (dest >= 0) {
-                        material_apply<D>(S, S.entity(ent)->material, t_d, true);
-                        material_apply<D>(S, S.entity((uint32_t)dest)->material, t_d, false);
-                        need_trans = true;
+                            for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
+                            dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
+                            if (dest >= 0) {
+                                material_apply<D>(S, S.entity(ent)->material, c_d[0], true);
+                                material_apply<D>(S, S.entity((uint32_t)dest)->material, c_d[0], false);
+                                need_trans = true;
+                            }
+                        }
+                    }
+                    const bool need_refl = !(ratio <= 0.0);                                /* get_reflection_color, surface.rs:119-139 */
+                    const uint32_t rs = need_trans ? 1u : 0u;        /* reflection goes to child slot rs in the arrays */
+                    if (need_refl) {
+                        const double dn = vdot<D>(c.dir, c.nc);
+#pragma unroll
+                        for (int k = 0; k < D; k++) {
+                            const double rd = c.nc[k] * -2.0 * dn + c.dir[k];              /* surface.rs:246-256 */
+                            const double ro = c.loc[k] + c.nc[k] * EU_EPS * 128.0;
+                            if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
+                        }
+                    }
+                    if (need_trans) {
+                        node_kind = need_refl ? WF_COMBINE_TRANS : WF_OVER;
+                        B.node_px[nid] = spx;
+                        if (need_refl) B.node_ratio[nid] = ratio;
+                        B.node_parent[nid] = parent;
+                        c_ent[0] = (uint32_t)dest; c_parent[0] = nid; c_slot[0] = 0u;
+                        n_child = 1;
+                        if (need_refl) { c_ent[1] = ent; c_parent[1] = nid; c_slot[1] = 1u; n_child = 2; }
+                    } else if (need_refl) {
+                        c_ent[0] = ent;
+                        n_child = 1;
+                        if (have_inter) {
+                            node_kind = WF_COMBINE_INTER;
+                            B.node_ratio[nid] = ratio;
+                            B.node_parent[nid] = parent;
+                            wf_deliver(B, nid, 0u, inter);
+                            c_parent[0] = nid; c_slot[0] = 1u;
+                        } else {   /* the reflection colour is the result (surface.rs:153-154): the child reports to our parent */
+                            c_parent[0] = parent; c_slot[0] = slot;
+                        }
+                    } else {
+                        if (!have_inter) cnt.errors++;            /* the reference panics here (surface.rs:154) */
+                        wf_deliver(B, parent, slot, inter);
                     }
                 }
+                B.node_meta[nid] = node_kind | (slot << 8);
             }
-            const bool need_refl = !(ratio <= 0.0);                                /* get_reflection_color, surface.rs:119-139 */
-            double r_o[D], r_d[D];
-            if (need_refl) {
-                const double dn = vdot<D>(c.dir, c.nc);
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    r_d[k] = c.nc[k] * -2.0 * dn + c.dir[k];                       /* surface.rs:246-256 */
-                    r_o[k] = c.loc[k] + c.nc[k] * EU_EPS * 128.0;
+            /* children with no depth left (or plain misses) only sample the background
+             * (universe/mod.rs:157,183): one code site for all of them */
+            uint32_t n_queue = 0;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 2; k++) {
+                if (k < n_child) {
+                    const bool bg_only = (c_slot[k] & 2u) != 0 || child_depth == 0;
+                    if (bg_only) wf_deliver(B, c_parent[k], c_slot[k] & 1u, wf_background<D>(S, c_d[k], cnt));
+                    else n_queue++;
                 }
             }
-            if (need_trans) {
-                node_kind = need_refl ? WF_COMBINE_TRANS : WF_OVER;
-                B.node_px[nid] = spx;
-                if (need_refl) B.node_ratio[nid] = ratio;
-                B.node_parent[nid] = parent;
-                wf_spawn<D>(S, B, counters, gen, child_depth, t_o, t_d, (uint32_t)dest, nid, 0u, cnt);
-                if (need_refl) wf_spawn<D>(S, B, counters, gen, child_depth, r_o, r_d, ent, nid, 1u, cnt);
-            } else if (need_refl) {
-                if (have_inter) {
-                    node_kind = WF_COMBINE_INTER;
-                    B.node_ratio[nid] = ratio;
-                    B.node_parent[nid] = parent;
-                    wf_deliver(B, nid, 0u, inter);
-                    wf_spawn<D>(S, B, counters, gen, child_depth, r_o, r_d, ent, nid, 1u, cnt);
-                } else {   /* the reflection colour is the result (surface.rs:153-154): the child reports to our parent */
-                    wf_spawn<D>(S, B, counters, gen, child_depth, r_o, r_d, ent, parent, slot, cnt);
-                }
-            } else {
-                if (!have_inter) cnt.errors++;            /* the reference panics here (surface.rs:154) */
-                wf_deliver(B, parent, slot, inter);
+            uint32_t pos1;
+            const uint32_t pos0 = wf_append_local(&seg_fill, n_queue, pos1);
+            if (n_queue >= 1) {
+                if (pos0 >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
+                else wf_store_ray<D>(B, outb, out_base + pos0, c_o[0], c_d[0], c_parent[0], c_ent[0] | (c_slot[0] << 16));
+            }
+            if (n_queue >= 2) {
+                if (pos1 >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
+                else wf_store_ray<D>(B, outb, out_base + pos1, c_o[1], c_d[1], c_parent[1], c_ent[1] | (c_slot[1] << 16));
             }
         }
-        B.node_meta[nid] = node_kind | (slot << 8);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
     wf_flush_counters(counters, cnt);
 }
 
@@ -340,32 +439,34 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
 template <int D>
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters) {
     LaneCounters cnt = {0, 0, 0, 0};
-    const unsigned long long count = counters->gen_count[gen] < B.ray_cap ? counters->gen_count[gen] : B.ray_cap;
-    unsigned long long gen_base = B.npix;
-    for (uint32_t h = 0; h < gen; h++) gen_base += counters->gen_count[h] < B.ray_cap ? counters->gen_count[h] : B.ray_cap;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long nid = gen_base + i;
-        if (nid >= B.node_cap) continue;
-        const uint32_t meta = B.node_meta[nid];
-        const uint32_t kind = meta & 0xffu;
-        if (kind == WF_NONE) continue;
-        const double *ch = B.node_child + (size_t)nid * 8;
-        Rgba c0 = {ch[0], ch[1], ch[2], ch[3]};
-        Rgba res;
-        if (kind == WF_COMBINE_INTER) {                                            /* surface.rs:159-161 */
-            const Rgba c1 = {ch[4], ch[5], ch[6], ch[7]};
-            res = combine_palette_color(c1, c0, B.node_ratio[nid]);
-        } else {
-            /* surface_palette.over(transition_palette), both re-quantised to u8 (surface.rs:104-114) */
-            const uint32_t tpx = to_pixel4(c0, cnt);
-            const Rgba inter = blend_rgba(EU_BL_OVER, new_u8(B.node_px[nid]), new_u8(tpx));
-            if (kind == WF_OVER) res = inter;
-            else {
+    const uint32_t node_base = B.npix + gen * B.ray_cap;
+    __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    {
+        for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+            const uint32_t nid = node_base + wf_map_index(pref, B.n_seg, B.seg_cap, v);
+            const uint32_t meta = B.node_meta[nid];
+            const uint32_t kind = meta & 0xffu;
+            if (kind == WF_NONE) continue;
+            const double *ch = B.node_child + (size_t)nid * 8;
+            Rgba c0 = {ch[0], ch[1], ch[2], ch[3]};
+            Rgba res;
+            if (kind == WF_COMBINE_INTER) {                                            /* surface.rs:159-161 */
                 const Rgba c1 = {ch[4], ch[5], ch[6], ch[7]};
-                res = combine_palette_color(c1, inter, B.node_ratio[nid]);
+                res = combine_palette_color(c1, c0, B.node_ratio[nid]);
+            } else {
+                /* surface_palette.over(transition_palette), both re-quantised to u8 (surface.rs:104-114) */
+                const uint32_t tpx = to_pixel4(c0, cnt);
+                const Rgba inter = blend_rgba(EU_BL_OVER, new_u8(B.node_px[nid]), new_u8(tpx));
+                if (kind == WF_OVER) res = inter;
+                else {
+                    const Rgba c1 = {ch[4], ch[5], ch[6], ch[7]};
+                    res = combine_palette_color(c1, inter, B.node_ratio[nid]);
+                }
             }
+            wf_deliver(B, B.node_parent[nid], (meta >> 8) & 1u, res);
         }
-        wf_deliver(B, B.node_parent[nid], (meta >> 8) & 1u, res);
     }
     wf_flush_counters(counters, cnt);
 }
