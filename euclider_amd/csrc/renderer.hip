@@ -285,7 +285,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     B.npix = df.single_pixel ? 1u : (uint32_t)pixels;
     const size_t scene_bytes = (size_t)r->scene_words * 8;
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
-    const size_t isect_lds = scene_bytes + (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;
+    const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
     if ((rc = wf_grid(r, eu_wf_intersect_kernel<D>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;

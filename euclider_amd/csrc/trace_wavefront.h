@@ -247,11 +247,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
                                                                       EuWfBuffers B, EuDevCounters *counters, double *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
-    S.init(wf_stage_scene(scene_g, scene_words, lds_dyn));
+    S.init(scene_g);
     HitStackLds HS;
     {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double *hs_t = (double *)(lds_dyn + scene_words);
+        double *hs_t = (double *)(lds_dyn);
         uint32_t *hs_c = (uint32_t *)(hs_t + (EU_WF_BLOCK / 64) * hs_cap * 64);
         HS.t = hs_t + wave * hs_cap * 64 + lane;
         HS.c = hs_c + wave * hs_cap * 64 + lane;
