@@ -293,7 +293,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
     for (uint32_t g = 0; g < dc.max_depth; g++) {
         hipLaunchKernelGGL(eu_wf_intersect_kernel<D>, dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
-        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
     }
     for (uint32_t g = dc.max_depth; g-- > 0;)
         hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
     EuScene S;
-    S.init(wf_stage_scene(scene_g, scene_words, lds_dyn));
+    S.init(scene_g);
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
