@@ -290,59 +290,80 @@ struct Rgba { double r, g, b, a; };
  * Level k merges the running stream S_{k-1} (an ordered list of leaf indices, 4 bits each) with the
  * single hit of leaf k, reproducing the iterator's three modes: both present (a failed test skips),
  * only a left (a failed test ends the stream), only b left. */
-template <int D, class HS>
+template <int D>
 EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const double *o, const double *d,
-                           HS &hs, uint32_t tk_base /* n free hit-stack slots for the t_k */, uint32_t &list_out) {
-    /* loops are kept rolled on purpose (uniform trip counts): small code, few live registers */
+                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out) {
+    /* Fully unrolled over the (at most 8) leaves with wave-uniform guards: the t_k and the hit points
+     * stay in registers, plane parameters arrive through scalar loads (uniform addresses), and every
+     * matrix entry costs one dot product, one compare and one bit insert. */
     uint32_t pres = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const double *Pk = P + k * EU_HS_STRIDE(D);
-        const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);          /* shape.rs:789-790 */
-        hs.set_t(tk_base + k, t);
-        if (!(t < 0.0)) pres |= 1u << k;
-    }
-    uint64_t IN = 0, LT = 0;          /* bit 8*j+i: leaf j contains hit i  /  t_i < t_j */
-    for (uint32_t i = 0; i < n; i++) {
-        const double ti = hs.gt(tk_base + i);
-        double loc[D];
 #pragma unroll
-        for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * ti;
-        for (uint32_t j = 0; j < n; j++) {
-            if (j == i) continue;
-            const double *Pj = P + j * EU_HS_STRIDE(D);
-            const double r = vdot<D>(Pj, loc) + Pj[D];
-            const uint64_t in = (Pj[D + 1] == rust_signum(r)) ? 1ull : 0ull;   /* shape.rs:874-880 */
-            const uint64_t lt = (ti < hs.gt(tk_base + j)) ? 1ull : 0ull;
-            IN |= in << (8 * j + i);
-            LT |= lt << (8 * j + i);
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        tk[k] = 0.0;
+        if (k < n) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
+            tk[k] = t;
+            if (!(t < 0.0)) pres |= 1u << k;
+        }
+    }
+    uint32_t in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];     /* in_k[j] bit i: leaf j contains hit i ; lt_k[j] bit i: t_i < t_j */
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
+        if (i < n) {
+            double loc[D];
+#pragma unroll
+            for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * tk[i];
+#pragma unroll
+            for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
+                if (j < n && j != i) {
+                    const double *Pj = P + j * EU_HS_STRIDE(D);
+                    const double r = vdot<D>(Pj, loc) + Pj[D];
+                    if (Pj[D + 1] == rust_signum(r)) in_k[j] |= 1u << i;       /* shape.rs:874-880 */
+                    if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
+                }
+            }
         }
     }
     uint32_t list = 0, len = (pres & 1u);
-    for (uint32_t k = 1; k < n; k++) {
-        /* inside_of_A(h_k): Intersection -> every earlier leaf contains it, Union -> any (shape.rs:591-594) */
-        const uint64_t colmask = 0x0101010101010101ull & ((1ull << (8 * k)) - 1ull);
-        const uint64_t col = (IN >> k) & colmask;
-        const bool bpass = is_union ? (col == 0) : (col == colmask);
-        const uint32_t ink = (uint32_t)(IN >> (8 * k)) & 0xffu, ltk = (uint32_t)(LT >> (8 * k)) & 0xffu;
-        bool bpend = (pres >> k) & 1u, term = false;
-        uint32_t out = 0, olen = 0;
-        for (uint32_t p = 0; p < k; p++) {
-            if (p < len && !term) {
-                const uint32_t a = (list >> (4 * p)) & 15u;
-                if (bpend && !((ltk >> a) & 1u)) {              /* b is closer (or tie / NaN): it goes first */
-                    bpend = false;
-                    if (bpass) { out |= k << (4 * olen); olen++; }
+#pragma unroll
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) {
+        if (k < n) {
+            /* inside_of_A(h_k): Intersection -> every earlier leaf contains it, Union -> any (shape.rs:591-594) */
+            bool all = true, any = false;
+#pragma unroll
+            for (uint32_t j = 0; j < k; j++) { const bool in = (in_k[j] >> k) & 1u; all = all && in; any = any || in; }
+            const bool bpass = is_union ? !any : all;
+            bool bpend = (pres >> k) & 1u, term = false;
+            uint32_t out = 0, olen = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < k; p++) {
+                if (p < len && !term) {
+                    const uint32_t a = (list >> (4 * p)) & 15u;
+                    if (bpend && !((lt_k[k] >> a) & 1u)) {          /* b is closer (or tie / NaN): it goes first */
+                        bpend = false;
+                        if (bpass) { out |= k << (4 * olen); olen++; }
+                    }
+                    const bool in = (in_k[k] >> a) & 1u;
+                    if (in != is_union) { out |= a << (4 * olen); olen++; }
+                    else if (!bpend) term = true;                   /* only a left and it fails: the stream ends */
                 }
-                const bool in = (ink >> a) & 1u;
-                if (in != is_union) { out |= a << (4 * olen); olen++; }
-                else if (!bpend) term = true;                   /* only a left and it fails: the stream ends */
             }
+            if (bpend && !term && bpass) { out |= k << (4 * olen); olen++; }
+            list = out; len = olen;
         }
-        if (bpend && !term && bpass) { out |= k << (4 * olen); olen++; }
-        list = out; len = olen;
     }
     list_out = list;
     return len;
+}
+
+EU_DEV double chain_t(const double (&tk)[EU_CHAIN_MAX], uint32_t idx) {
+    double t = tk[0];
+#pragma unroll
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (idx == k) t = tk[k];
+    return t;
 }
 
 /* ------------------------------------------------------------------ CSG: eager post-order evaluation */
@@ -355,9 +376,9 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         uint32_t kind, f, param, count;
         S.op(root, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
-            uint32_t list;
-            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, hs, 0u, list);
-            if (n) { first_t = hs.gt(list & 15u); first_c = root | ((list & 15u) << 16); }
+            double tk[EU_CHAIN_MAX]; uint32_t list;
+            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            if (n) { first_t = chain_t(tk, list & 15u); first_c = root | ((list & 15u) << 16); }
             return n;
         }
         double t0 = 0.0, t1 = 0.0;
@@ -372,12 +393,12 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         uint32_t kind, f, param, count;
         S.op(i, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
-            uint32_t list = 0, n = 0;
-            if (sp + 2 * count > CAP) cnt.errors++;       /* count slots for the list + count for the t_k */
-            else n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, hs, sp + count, list);
+            double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
+            if (sp + count > CAP) cnt.errors++;
+            else n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
             for (uint32_t p = 0; p < n; p++) {
                 const uint32_t idx = (list >> (4 * p)) & 15u;
-                hs.set(sp + p, hs.gt(sp + count + idx), i | (idx << 16));
+                hs.set(sp + p, chain_t(tk, idx), i | (idx << 16));
             }
             sp += n;
             lens = (lens << 8) | (uint64_t)n;
