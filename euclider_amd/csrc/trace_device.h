@@ -623,7 +623,7 @@ EU_DEV Rgba from_premultiplied(Rgba p) {
     c.a = a;
     return c;
 }
-EU_DEV double blend_chan(uint32_t fn, double a, double b, double sa, double da) {
+__device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, double sa, double da) {
     const double one = 1.0, two = 2.0;
     switch (fn) {
     case EU_BL_OVER: return a + b * (one - sa);
@@ -675,10 +675,28 @@ EU_DEV double blend_alpha(uint32_t fn, double sa, double da) {
 }
 EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
     Rgba o;
-    o.r = blend_chan(fn, s.r, d.r, s.a, d.a);
-    o.g = blend_chan(fn, s.g, d.g, s.a, d.a);
-    o.b = blend_chan(fn, s.b, d.b, s.a, d.a);
-    o.a = blend_alpha(fn, s.a, d.a);
+    const double one = 1.0, two = 2.0, sa = s.a, da = d.a;
+    switch (fn) {      /* the modes the shipped scenes use are expanded in line; the rest go through blend_chan */
+    case EU_BL_OVER:
+        o.r = s.r + d.r * (one - sa); o.g = s.g + d.g * (one - sa); o.b = s.b + d.b * (one - sa);
+        break;
+    case EU_BL_DARKEN:
+        o.r = rust_min(s.r * da, d.r * sa) + s.r * (one - da) + d.r * (one - sa);
+        o.g = rust_min(s.g * da, d.g * sa) + s.g * (one - da) + d.g * (one - sa);
+        o.b = rust_min(s.b * da, d.b * sa) + s.b * (one - da) + d.b * (one - sa);
+        break;
+    case EU_BL_DIFFERENCE:
+        o.r = s.r + d.r - two * rust_min(s.r * da, d.r * sa);
+        o.g = s.g + d.g - two * rust_min(s.g * da, d.g * sa);
+        o.b = s.b + d.b - two * rust_min(s.b * da, d.b * sa);
+        break;
+    default:
+        o.r = blend_chan(fn, s.r, d.r, sa, da);
+        o.g = blend_chan(fn, s.g, d.g, sa, da);
+        o.b = blend_chan(fn, s.b, d.b, sa, da);
+        break;
+    }
+    o.a = blend_alpha(fn, sa, da);
     return o;
 }
 EU_DEV Rgba blend_rgba(uint32_t fn, Rgba s, Rgba d) { return from_premultiplied(blend_pre(fn, into_premultiplied(s), into_premultiplied(d))); }   /* surface.rs:315-322 */
@@ -730,7 +748,7 @@ EU_DEV double pgrad4(int hash, double x, double y, double z, double w) {
     return ((h & 1) ? -a : a) + ((h & 2) ? -b : b) + ((h & 4) ? -c : c);
 }
 EU_DEV int pcell(double f) { double m = fmod(f, 256.0); return (m == m) ? (((int)m) & 255) : 0; }
-EU_DEV double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
+__device__ __noinline__ double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
     double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
     int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
     double xf = x - fx, yf = y - fy, zf = z - fz, wf = w - fw;
@@ -806,25 +824,66 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
 }
 
 /* ------------------------------------------------------------------ surface providers */
-template <int D> struct HitCtx {      /* TracingContext, shape.rs:111-125 */
+/* TracingContext (shape.rs:111-125) plus a cache of the angles the providers keep asking for.
+ *
+ * The reference calls angle_between (util.rs:712-722: acos(a.b / (|a||b|)), NaN -> 0) once in
+ * trace_closest (direction vs normal, universe/mod.rs:118), again in the Fresnel ratio and in Snell
+ * (direction vs -normal_closer, surface.rs:219,274) and again in both illumination providers
+ * (surface.rs:399,415).  normal_closer is +-normal, negation is exact and IEEE division is
+ * sign-symmetric, so all of them are acos(+x_e) or acos(-x_e) of ONE quotient
+ *     x_e = dot(direction, normal) / (|direction| * |normal|)
+ * and each value is computed at most once per hit, bit-identical to the separate evaluations. */
+template <int D> struct HitCtx {
     double loc[D], dir[D], normal[D], nc[D];
     bool exiting;
+    double x_e, ang_e;          /* ang_e = angle_between(direction, normal) */
+    double ang_me;              /* acos(-x_e), NaN -> 0; valid when have_me */
+    bool have_me;
+    double sin_from, to_mult, to_theta;   /* Fresnel / Snell: sin(from_theta); asin(to_mult * sin_from) */
+    bool have_sin, have_to;
+
+    EU_DEV void finish(double best_t, const double *o, const double *d) {
+#pragma unroll
+        for (int k = 0; k < D; k++) { loc[k] = o[k] + d[k] * best_t; dir[k] = d[k]; }
+    }
+    EU_DEV void classify() {    /* universe/mod.rs:118-125 */
+        x_e = vdot<D>(dir, normal) / (vnorm<D>(dir) * vnorm<D>(normal));
+        const double r = eu_acos(x_e);
+        ang_e = (r != r) ? 0.0 : r;
+        have_me = false; have_sin = false; have_to = false;
+        exiting = ang_e < EU_FRAC_PI_2_C;
+#pragma unroll
+        for (int k = 0; k < D; k++) nc[k] = exiting ? -normal[k] : normal[k];
+    }
+    EU_DEV double angle_neg() {
+        if (!have_me) { const double r = eu_acos(-x_e); ang_me = (r != r) ? 0.0 : r; have_me = true; }
+        return ang_me;
+    }
+    EU_DEV double angle_dir_nc() { return exiting ? angle_neg() : ang_e; }          /* angle_between(nc, dir) */
+    EU_DEV double angle_dir_minus_nc() { return exiting ? ang_e : angle_neg(); }    /* angle_between(dir, -nc) */
+    EU_DEV double sin_from_theta() {
+        if (!have_sin) { sin_from = eu_sin(angle_dir_minus_nc()); have_sin = true; }
+        return sin_from;
+    }
+    EU_DEV double to_theta_for(double mult) {                                        /* asin(mult * sin(from_theta)) */
+        if (have_to && mult == to_mult) return to_theta;
+        to_mult = mult; to_theta = eu_asin(mult * sin_from_theta()); have_to = true;
+        return to_theta;
+    }
 };
 
-template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, const HitCtx<D> &c) {
+template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, HitCtx<D> &c) {
     if (F->ratio_kind == EU_RATIO_UNIFORM) return c.exiting ? 0.0 : F->ratio_p0;     /* surface.rs:200-211 */
-    double normal[D];                                                                 /* surface.rs:213-244 */
-#pragma unroll
-    for (int i = 0; i < D; i++) normal[i] = -c.nc[i];
-    double from_theta = angle_between<D>(c.dir, normal);
-    double from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
-    double to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
-    double to_theta = eu_asin((from_index / to_index) * eu_sin(from_theta));
+    const double from_theta = c.angle_dir_minus_nc();                                 /* surface.rs:213-244 */
+    const double from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
+    const double to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
+    const double to_theta = c.to_theta_for(from_index / to_index);
     if (to_theta != to_theta) return 1.0;
-    double p1s = from_index * eu_cos(from_theta);
-    double p2s = to_index * eu_cos(to_theta);
-    double p1p = from_index * eu_cos(to_theta);
-    double p2p = to_index * eu_cos(from_theta);
+    const double cos_from = eu_cos(from_theta), cos_to = eu_cos(to_theta);
+    double p1s = from_index * cos_from;
+    double p2s = to_index * cos_to;
+    double p1p = from_index * cos_to;
+    double p2p = to_index * cos_from;
     double rs = (p1s - p2s) / (p1s + p2s); rs = rs * rs;
     double rp = (p1p - p2p) / (p1p + p2p); rp = rp * rp;
     return (rs + rp) / (1.0 + 1.0);
@@ -899,23 +958,23 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int r = 0; r < D; r++) vec[r] = out[r];
 }
 
-template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, const HitCtx<D> &c, double *out) {
+template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, HitCtx<D> &c, double *out) {
 #pragma unroll
     for (int i = 0; i < D; i++) out[i] = c.dir[i];
     if (F->thr_kind == EU_THR_IDENTITY) return;                     /* surface.rs:258-266 */
     double normal[D];                                               /* surface.rs:268-288 */
 #pragma unroll
     for (int i = 0; i < D; i++) normal[i] = -c.nc[i];
-    double from_theta = angle_between<D>(c.dir, normal);
-    double modifier = c.exiting ? F->thr_p0 : F->thr_p0_inv;
-    double to_theta = eu_asin(modifier * eu_sin(from_theta));
-    double angle_delta = to_theta - from_theta;
+    const double from_theta = c.angle_dir_minus_nc();
+    const double modifier = c.exiting ? F->thr_p0 : F->thr_p0_inv;
+    const double to_theta = c.to_theta_for(modifier);
+    const double angle_delta = to_theta - from_theta;
     general_rotation<D>(normal, c.dir, angle_delta, out);
 }
 
 /* the surface-colour provider tree, evaluated as a post-order program on a small stack */
 template <int D>
-EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, const HitCtx<D> &c, double time_s, LaneCounters &cnt) {
+EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c, double time_s, LaneCounters &cnt) {
     Rgba st[4];
     int sp = 0;
     for (uint32_t i = F->color_first; i <= F->color_root; i++) {
@@ -930,7 +989,7 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, const HitCtx
             break;
         }
         case EU_COL_ILLUM_GLOBAL: {                                                           /* surface.rs:410-422 */
-            double original_angle = angle_between<D>(c.nc, c.dir);
+            double original_angle = c.angle_dir_nc();
             double angle = EU_PI_C - original_angle;
             double ratio = angle / EU_FRAC_PI_2_C;
             v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
@@ -940,7 +999,7 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, const HitCtx
             double normal[D];
 #pragma unroll
             for (int k = 0; k < D; k++) normal[k] = c.normal[k];
-            if (angle_between<D>(c.dir, normal) > EU_FRAC_PI_2_C) {
+            if (c.ang_e > EU_FRAC_PI_2_C) {
 #pragma unroll
                 for (int k = 0; k < D; k++) normal[k] = -normal[k];
             }

@@ -170,12 +170,9 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
             if (have) {
                 /* ComposableSurface::get_color (surface.rs:62-162) */
                 HitCtx<D> c;
-#pragma unroll
-                for (int i = 0; i < D; i++) { c.loc[i] = o[i] + d[i] * best_t; c.dir[i] = d[i]; }
+                c.finish(best_t, o, d);
                 hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
-                c.exiting = angle_between<D>(c.dir, c.normal) < EU_FRAC_PI_2_C;      /* universe/mod.rs:118-125 */
-#pragma unroll
-                for (int i = 0; i < D; i++) c.nc[i] = c.exiting ? -c.normal[i] : c.normal[i];
+                c.classify();
                 const EuFlatEntity *HE = S.entity(best_ent);
                 const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
                 double ratio = reflection_ratio<D>(F, c);

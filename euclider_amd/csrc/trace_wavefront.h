@@ -33,6 +33,16 @@
 #include "trace_device.h"
 
 #define EU_WF_BLOCK 256
+#define EU_WF_WIN 1024        /* rays sorted together in the shade kernel */
+#define EU_WF_KEYS 32
+
+/* Diagnostic build only (-DEU_PROFILE_PHASES): s_memtime shares of the shade kernel's sections go to
+ * EuDevCounters::phase[]; never to an output.  WF_STAMP(k) closes section k-1 and opens section k. */
+#ifdef EU_PROFILE_PHASES
+#define WF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[(k) - 1] += now_ - last_; last_ = now_; } while (0)
+#else
+#define WF_STAMP(k) do { } while (0)
+#endif
 
 enum { WF_NONE = 0, WF_ROOT = 1, WF_OVER = 2, WF_COMBINE_TRANS = 3, WF_COMBINE_INTER = 4 };
 
@@ -300,6 +310,9 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
     EuScene S;
     S.init(scene_g);
     LaneCounters cnt = {0, 0, 0, 0};
+#ifdef EU_PROFILE_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#endif
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
     const uint32_t out_base = blockIdx.x * B.seg_cap;
@@ -307,19 +320,50 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    /* Rays are taken in windows of EU_WF_WIN per workgroup and counting-sorted in LDS by the entity they
+     * hit, so that a wave shades (mostly) one surface: a wall ray costs ~500 instructions, a glass ray
+     * (Fresnel + Snell + rotation) ~2500, and unsorted they would share waves. */
+    __shared__ uint32_t sorted[EU_WF_WIN];
+    __shared__ uint32_t hist[EU_WF_KEYS], offs[EU_WF_KEYS];
     {
-        const uint32_t stride = gridDim.x * blockDim.x;
+        const uint32_t stride = gridDim.x * EU_WF_WIN;
         const uint32_t iters = (total + stride - 1) / stride;             /* whole iterations: block-wide append below */
         for (uint32_t it = 0; it < iters; it++) {
-            const uint32_t v = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-            const bool live = v < total;
-            const uint32_t i = live ? wf_map_index(pref, B.n_seg, B.seg_cap, v) : 0u;
+            const uint32_t wbase = it * stride + blockIdx.x * EU_WF_WIN;
+            if (threadIdx.x < EU_WF_KEYS) hist[threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t myq[EU_WF_WIN / EU_WF_BLOCK], mykey[EU_WF_WIN / EU_WF_BLOCK], myrank[EU_WF_WIN / EU_WF_BLOCK];
+#pragma unroll
+            for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
+                const uint32_t v = wbase + k * EU_WF_BLOCK + threadIdx.x;
+                mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
+                if (v < total) {
+                    myq[k] = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+                    const uint32_t he = B.hit_ent[myq[k]];
+                    mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
+                    myrank[k] = atomicAdd(&hist[mykey[k]], 1u);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) if (mykey[k] != 0xffffffffu) sorted[offs[mykey[k]] + myrank[k]] = myq[k];
+            __syncthreads();
+            const uint32_t n_live = wbase < total ? (total - wbase < EU_WF_WIN ? total - wbase : EU_WF_WIN) : 0u;
+#pragma unroll 1
+            for (uint32_t sub = 0; sub < EU_WF_WIN / EU_WF_BLOCK; sub++) {
+            const uint32_t sidx = sub * EU_WF_BLOCK + threadIdx.x;
+            const bool live = sidx < n_live;
+            const uint32_t i = live ? sorted[sidx] : 0u;
+            WF_STAMP(0);
             const uint32_t nid = node_base + i;
             /* children of this ray: 0 = transmission, 1 = reflection */
             uint32_t n_child = 0;
             double c_o[2][D], c_d[2][D];
             uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_slot[2] = {0, 0};
             if (live) {
+                WF_STAMP(1);
                 const uint32_t parent = B.ray_parent[in][i];
                 const uint32_t aux = B.ray_aux[in][i];
                 const uint32_t ent = aux & 0xffffu, slot = (aux >> 16) & 1u;
@@ -338,17 +382,16 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
                     const double best_t = B.hit_t[i];
                     const uint32_t best_code = B.hit_code[i];
                     HitCtx<D> c;
-#pragma unroll
-                    for (int k = 0; k < D; k++) { c.loc[k] = o[k] + d[k] * best_t; c.dir[k] = d[k]; }
+                    c.finish(best_t, o, d);
                     hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
-                    c.exiting = angle_between<D>(c.dir, c.normal) < EU_FRAC_PI_2_C;      /* universe/mod.rs:118-125 */
-#pragma unroll
-                    for (int k = 0; k < D; k++) c.nc[k] = c.exiting ? -c.normal[k] : c.normal[k];
+                    c.classify();
+                    WF_STAMP(2);
                     const EuFlatEntity *HE = S.entity(hit_ent);
                     const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
                     double ratio = reflection_ratio<D>(F, c);
                     ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
 
+                    WF_STAMP(3);
                     bool have_inter = false, need_trans = false;
                     Rgba inter = {0.0, 0.0, 0.0, 0.0};
                     uint32_t spx = 0;
@@ -369,6 +412,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
                             }
                         }
                     }
+                    WF_STAMP(4);
                     const bool need_refl = !(ratio <= 0.0);                                /* get_reflection_color, surface.rs:119-139 */
                     const uint32_t rs = need_trans ? 1u : 0u;        /* reflection goes to child slot rs in the arrays */
                     if (need_refl) {
@@ -409,6 +453,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
             }
             /* children with no depth left (or plain misses) only sample the background
              * (universe/mod.rs:157,183): one code site for all of them */
+            WF_STAMP(5);
             uint32_t n_queue = 0;
 #pragma unroll 1
             for (uint32_t k = 0; k < 2; k++) {
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
                     else n_queue++;
                 }
             }
+            WF_STAMP(6);
             uint32_t pos1;
             const uint32_t pos0 = wf_append_local(&seg_fill, n_queue, pos1);
             if (n_queue >= 1) {
@@ -428,9 +474,19 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
                 if (pos1 >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
                 else wf_store_ray<D>(B, outb, out_base + pos1, c_o[1], c_d[1], c_parent[1], c_ent[1] | (c_slot[1] << 16));
             }
+            WF_STAMP(7);
+            }   /* sub */
+            __syncthreads();     /* `sorted` is rewritten by the next window */
         }
     }
     __syncthreads();
+#ifdef EU_PROFILE_PHASES
+    for (int q = 0; q < 8; q++) {
+        unsigned long long v = ph[q];
+        for (int off = 32; off > 0; off >>= 1) { unsigned long long w2 = __shfl_down(v, off); v = w2 > v ? w2 : v; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters->phase[q], v);
+    }
+#endif
     if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
     wf_flush_counters(counters, cnt);
 }

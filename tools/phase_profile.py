@@ -19,7 +19,7 @@ for _ in range(2):
 ph = (C.c_uint64 * 8)()
 _capi.lib().eu_renderer_debug_phases(env.renderer(0), ph)
 tot = float(sum(ph)) or 1.0
-names = ["refill+primary setup", "intersect (trace_closest)", "shade / background", "return frames"]
+names = ["load ray+hit", "normal+exiting", "reflection ratio", "surface colour+threshold dir+material_at", "reflection dir+node writes", "background samples", "append+store children", "-"]
 print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"])
 for i, n in enumerate(names):
     print("  %-28s %6.2f%%  (%d cycles)" % (n, 100.0 * ph[i] / tot, ph[i]))
