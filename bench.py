@@ -125,9 +125,8 @@ def main():
     rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(rgba) for _ in range(world)]
-        rows = torch.arange(H, device=dev)
-        strip = rows // 8
-        perm = (strip % world) * max_rows + (strip // world) * 8 + (rows % 8)
+        from euclider_amd.partition import gather_permutation
+        perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
         full = torch.empty((H, W), dtype=torch.int32, device=dev)
 
     def step():
