@@ -749,7 +749,7 @@ struct Flattener {
             for (auto *leaf : chain) push_halfspace_params(*leaf);
             n_leaves += (uint32_t)chain.size();
             len = (uint32_t)chain.size();
-            uint32_t use = base_use + len;
+            uint32_t use = base_use + 2 * len;               /* the list + slots for the t_k (picked by run-time index) */
             if (use > hit_cap) hit_cap = use;
             if (depth + 1 > list_depth) list_depth = depth + 1;
         } else if (s.kind == Shape::ComposableShape) {

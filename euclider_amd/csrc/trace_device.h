@@ -359,13 +359,6 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
     return len;
 }
 
-EU_DEV double chain_t(const double (&tk)[EU_CHAIN_MAX], uint32_t idx) {
-    double t = tk[0];
-#pragma unroll
-    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (idx == k) t = tk[k];
-    return t;
-}
-
 /* ------------------------------------------------------------------ CSG: eager post-order evaluation */
 /* Evaluates entity shape program ops[first..root] for ray (o, d); returns the number of hits of the
  * entity's stream and its first element (only that is used by trace_closest, universe/mod.rs:114). */
@@ -378,7 +371,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list;
             const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
-            if (n) { first_t = chain_t(tk, list & 15u); first_c = root | ((list & 15u) << 16); }
+            if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
+#pragma unroll
+                for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
+                first_t = hs.gt(list & 15u); first_c = root | ((list & 15u) << 16);
+            }
             return n;
         }
         double t0 = 0.0, t1 = 0.0;
@@ -394,11 +391,15 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         S.op(i, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
-            if (sp + count > CAP) cnt.errors++;
+            if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
             else n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            if (n) {
+#pragma unroll
+                for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
+            }
             for (uint32_t p = 0; p < n; p++) {
                 const uint32_t idx = (list >> (4 * p)) & 15u;
-                hs.set(sp + p, chain_t(tk, idx), i | (idx << 16));
+                hs.set(sp + p, hs.gt(sp + count + idx), i | (idx << 16));
             }
             sp += n;
             lens = (lens << 8) | (uint64_t)n;
