@@ -67,7 +67,7 @@ struct EuFlatHeader {
     uint32_t list_depth, color_depth;        /* max simultaneous hit lists / colour stack depth */
     uint32_t rpn_depth, flags;
     uint32_t n_params, off_params;           /* leaf parameter doubles */
-    uint32_t reserved0, reserved1;
+    uint32_t n_bounds, off_bounds;           /* bounding spheres of bounded entities: c[D], r2, far2 (D+2 doubles each) */
 };
 #define EU_FLAT_HEADER_WORDS 16
 
@@ -88,7 +88,7 @@ struct EuFlatEntity {
     uint16_t material;
     int16_t surface;     /* -1: no surface (Void / new_without_surface) */
     uint32_t max_hits;   /* static bound of hit-stack use for this entity */
-    uint32_t reserved;
+    uint32_t bound;      /* index into the bounds table, 0xffffffff: unbounded (never culled) */
 };
 
 struct EuFlatMaterial {

@@ -4,6 +4,7 @@
  */
 #include "scene_host.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -796,6 +797,85 @@ struct Flattener {
         return len;
     }
 
+    /* ---- conservative bounding spheres (exact culling, DESIGN.md "Culling") ---- */
+    struct Bound { bool ok = false; double c[MAXD] = {0, 0, 0, 0}; double r = 0.0; };
+    std::vector<double> bounds;
+
+    static Bound enclose(int D, const Bound &a, const Bound &b) {
+        Bound o;
+        if (!a.ok || !b.ok) return o;
+        double dist2 = 0.0;
+        for (int i = 0; i < D; i++) dist2 += (a.c[i] - b.c[i]) * (a.c[i] - b.c[i]);
+        const double dist = sqrt(dist2);
+        if (dist + b.r <= a.r) return a;
+        if (dist + a.r <= b.r) return b;
+        o.ok = true;
+        o.r = (dist + a.r + b.r) / 2.0;
+        for (int i = 0; i < D; i++) o.c[i] = a.c[i] + (b.c[i] - a.c[i]) * ((o.r - a.r) / dist);
+        return o;
+    }
+
+    /* an Intersection chain of axis-aligned half-spaces that bounds every axis on both sides (cuboid, hypercuboid) */
+    Bound box_bound(const std::vector<const Shape *> &leaves) const {
+        Bound o;
+        double lo[MAXD], hi[MAXD]; bool has_lo[MAXD] = {false, false, false, false}, has_hi[MAXD] = {false, false, false, false};
+        for (auto *s : leaves) {
+            if (s->kind != Shape::HalfSpace || !(s->signum == 1.0 || s->signum == -1.0)) return o;
+            int axis = -1;
+            for (int i = 0; i < D; i++) if (s->a[i] != 0.0) { if (axis >= 0) return o; axis = i; }
+            if (axis < 0) return o;
+            const double sn = s->a[axis], edge = -s->r / sn;          /* inside <=> sign(sn*x + c) == signum */
+            if (!std::isfinite(edge)) return o;
+            if (s->signum * sn > 0.0) { if (!has_lo[axis] || edge > lo[axis]) lo[axis] = edge; has_lo[axis] = true; }
+            else { if (!has_hi[axis] || edge < hi[axis]) hi[axis] = edge; has_hi[axis] = true; }
+        }
+        double r2 = 0.0;
+        for (int i = 0; i < D; i++) {
+            if (!has_lo[i] || !has_hi[i] || !(hi[i] >= lo[i])) return o;
+            o.c[i] = (lo[i] + hi[i]) / 2.0;
+            r2 += ((hi[i] - lo[i]) / 2.0) * ((hi[i] - lo[i]) / 2.0);
+        }
+        o.r = sqrt(r2); o.ok = true;
+        return o;
+    }
+
+    Bound shape_bound(const Shape &s) const {
+        Bound o;
+        switch (s.kind) {
+        case Shape::Sphere:
+            if (!(s.r > 0.0) || !std::isfinite(s.r)) return o;
+            o.ok = true; o.r = s.r;
+            for (int i = 0; i < D; i++) o.c[i] = s.a[i];
+            return o;
+        case Shape::ComposableShape: {
+            if (s.operation == SetOperation::Intersection) {
+                std::vector<const Shape *> chain;
+                if (collect_chain(s, SetOperation::Intersection, chain)) { Bound b = box_bound(chain); if (b.ok) return b; }
+                Bound a = shape_bound(*s.sa), b = shape_bound(*s.sb);
+                if (a.ok && b.ok) return a.r <= b.r ? a : b;
+                return a.ok ? a : b;
+            }
+            if (s.operation == SetOperation::Complement) return shape_bound(*s.sa);
+            return enclose(D, shape_bound(*s.sa), shape_bound(*s.sb));       /* Union, SymmetricDifference */
+        }
+        default: return o;     /* half-spaces, planes, infinite cylinders, VoidShape */
+        }
+    }
+
+    uint32_t entity_bound(const Shape &s) {
+        Bound b = shape_bound(s);
+        if (!b.ok || !(b.r > 0.0)) return 0xffffffffu;
+        double cmax = 0.0;
+        for (int i = 0; i < D; i++) { if (!std::isfinite(b.c[i])) return 0xffffffffu; cmax = std::max(cmax, fabs(b.c[i])); }
+        if (cmax > 1.0e6 * b.r) return 0xffffffffu;          /* the margin below must dominate rounding of |o - c|^2 */
+        const double rr = b.r * (1.0 + 1.0e-6) + 1.0e-9 * std::max(1.0, cmax);
+        uint32_t id = (uint32_t)(bounds.size() / (size_t)(D + 2));
+        for (int i = 0; i < D; i++) bounds.push_back(b.c[i]);
+        bounds.push_back(rr * rr);
+        bounds.push_back(1.0e8 * rr * rr);
+        return id;
+    }
+
     uint64_t emit_expr(const Expr &e, const std::string &legend) {
         uint32_t off = (uint32_t)code.size();
         for (auto &t : e.rpn) {
@@ -933,6 +1013,7 @@ FlatScene flatten(const Universe &u) {
         f.emit_shape(*e->shape, 0, 0);
         fe.shape_root = (uint16_t)(f.ops.size() - 1);
         fe.max_hits = f.hit_cap;
+        fe.bound = e->surface ? f.entity_bound(*e->shape) : 0xffffffffu;
         if (before_cap > f.hit_cap) f.hit_cap = before_cap;
         fe.material = (uint16_t)f.material_id(e->material);
         fe.surface = e->surface ? (int16_t)f.surface_id(e->surface) : (int16_t)-1;
@@ -963,6 +1044,7 @@ FlatScene flatten(const Universe &u) {
     h.n_color_ops = (uint32_t)f.color_ops.size(); h.off_color_ops = append(f.color_ops.data(), f.color_ops.size() * sizeof(EuFlatColorOp));
     h.n_mapped = (uint32_t)f.mapped.size(); h.off_mapped = append(f.mapped.data(), f.mapped.size() * sizeof(EuFlatMapped));
     h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
+    h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * 8);
     h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
     h.n_words = (uint32_t)w.size();
     memcpy(w.data(), &h, sizeof h);

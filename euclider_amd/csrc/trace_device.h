@@ -61,7 +61,7 @@ struct EuDevCounters {      /* device memory, zeroed before each launch */
 struct EuScene {
     const uint64_t *w;      /* blob (LDS or global) */
     uint32_t off_ops, off_params, off_entities, n_entities, off_materials, off_transforms, off_code;
-    uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background;
+    uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background, off_bounds;
 
     EU_DEV void init(const uint64_t *base) {
         w = base;
@@ -69,7 +69,7 @@ struct EuScene {
         off_ops = h->off_ops; off_params = h->off_params; off_entities = h->off_entities; n_entities = h->n_entities;
         off_materials = h->off_materials; off_transforms = h->off_transforms; off_code = h->off_code;
         off_surfaces = h->off_surfaces; off_color_ops = h->off_color_ops; off_mapped = h->off_mapped;
-        off_perlin = h->off_perlin; background = h->background;
+        off_perlin = h->off_perlin; background = h->background; off_bounds = h->off_bounds;
     }
     EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
     EU_DEV double dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
@@ -82,6 +82,7 @@ struct EuScene {
     EU_DEV const EuFlatSurface *surface(uint32_t s) const { return (const EuFlatSurface *)(w + off_surfaces + 8 * s); }
     EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
     EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
+    EU_DEV const double *bounds(uint32_t b, int D) const { return (const double *)(w + off_bounds + (uint32_t)(D + 2) * b); }
     EU_DEV const uint8_t *perlin(uint32_t p) const { return (const uint8_t *)(w + off_perlin + 64 * p); }
 };
 
@@ -479,6 +480,31 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     const uint32_t n = (uint32_t)(lens & 0x7f);
     if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
     return n;
+}
+
+/* Exact culling.  The loader gives every bounded entity (sphere, cuboid / hypercuboid, and Union /
+ * Intersection / Complement / SymmetricDifference trees over them) a bounding sphere enlarged by 1e-6.
+ * If the half-line o + d*t, t >= 0, stays outside it, no hit point of any leaf of the entity lies in the
+ * entity's shape: every hit point of a box chain violates one of the other half-spaces by a margin that
+ * dwarfs rounding (so the chain's hit stream is empty), a sphere's own discriminant is negative, and an
+ * operand that is not bounded only contributes points that fail the bounded operand's is_point_inside.
+ * The entity's stream is therefore empty and trace_closest would skip it anyway (universe/mod.rs:114):
+ * skipping the evaluation changes nothing.  NaN anywhere makes every comparison false: no culling. */
+template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o, const double *d) {
+    double rel[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) rel[i] = o[i] - Bd[i];
+    const double rr = vdot<D>(rel, rel);
+    const double cc = rr - Bd[D];
+    if (cc > 0.0) {                                   /* origin outside the enlarged sphere */
+        const double b = vdot<D>(d, rel);
+        if (b >= 0.0) return true;                    /* moving away: the closest point is the origin */
+        if (rr < Bd[D + 1]) {                         /* discriminant margin only holds for |o-c| < 1e4 R */
+            const double a = vdot<D>(d, d);
+            if (b * b - a * cc < 0.0) return true;    /* the whole line misses */
+        }
+    }
+    return false;
 }
 
 /* normal of the hit described by `code` at parameter t (recomputed from the leaf) */

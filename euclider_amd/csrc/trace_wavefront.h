@@ -286,6 +286,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuFlatEntity *E = S.entity(e);
                 if (E->surface < 0) continue;
+                if (E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d)) continue;
                 double t = 0.0; uint32_t code = 0;
                 const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
