@@ -392,13 +392,13 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
     return EU_OK;
 }
 
-extern "C" int eu_renderer_debug_phases(eu_renderer *r, unsigned long long out[8]) {
+extern "C" int eu_renderer_debug_phases(eu_renderer *r, unsigned long long out[16]) {
     if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->last_stream));
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++) out[i] = c.phase[i];
+    for (int i = 0; i < 16; i++) out[i] = c.phase[i];
     return EU_OK;
 }
 

@@ -52,7 +52,7 @@ struct EuDevFrame {
 struct EuDevCounters {      /* device memory, zeroed before each launch */
     unsigned long long next_item;
     unsigned long long rays, bg_samples, nan_pixels, errors;
-    unsigned long long phase[8];   /* diagnostic builds only */
+    unsigned long long phase[16];  /* diagnostic builds only */
     unsigned long long gen_count[EU_MAX_DEPTH + 2];   /* wavefront pipeline: rays queued per generation */
     unsigned long long overflow;                      /* rays / nodes dropped because a queue was full */
 };

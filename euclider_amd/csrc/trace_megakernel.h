@@ -52,7 +52,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
     FrameStack<D> FS;
     LaneCounters cnt = {0, 0, 0, 0};
 #ifdef EU_PROFILE_PHASES
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;

@@ -39,9 +39,11 @@
 /* Diagnostic build only (-DEU_PROFILE_PHASES): s_memtime shares of the shade kernel's sections go to
  * EuDevCounters::phase[]; never to an output.  WF_STAMP(k) closes section k-1 and opens section k. */
 #ifdef EU_PROFILE_PHASES
-#define WF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[(k) - 1] += now_ - last_; last_ = now_; } while (0)
+#define WF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[(k) - 1] += now_ - last_; last_ = now_; last2_ = now_; } while (0)
+#define WF_SUB(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last2_; last2_ = now_; } while (0)
 #else
 #define WF_STAMP(k) do { } while (0)
+#define WF_SUB(k) do { } while (0)
 #endif
 
 enum { WF_NONE = 0, WF_ROOT = 1, WF_OVER = 2, WF_COMBINE_TRANS = 3, WF_COMBINE_INTER = 4 };
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
     S.init(scene_g);
     LaneCounters cnt = {0, 0, 0, 0};
 #ifdef EU_PROFILE_PHASES
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, last2_ = 0;
 #endif
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
@@ -399,13 +401,17 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
                     int dest = -1;
                     if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
                         const Rgba sc = surface_color<D>(S, F, c, time_s, cnt);
+                        WF_SUB(8);
                         spx = to_pixel4(sc, cnt);
+                        WF_SUB(9);
                         if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
                         else {
                             threshold_direction<D>(F, c, c_d[0]);
+                            WF_SUB(10);
 #pragma unroll
                             for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
                             dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
+                            WF_SUB(11);
                             if (dest >= 0) {
                                 material_apply<D>(S, S.entity(ent)->material, c_d[0], true);
                                 material_apply<D>(S, S.entity((uint32_t)dest)->material, c_d[0], false);
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t
     }
     __syncthreads();
 #ifdef EU_PROFILE_PHASES
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < 16; q++) {
         unsigned long long v = ph[q];
         for (int off = 32; off > 0; off >>= 1) { unsigned long long w2 = __shfl_down(v, off); v = w2 > v ? w2 : v; }
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters->phase[q], v);

@@ -123,7 +123,7 @@ int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
 
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
  * (refill, intersect, shade, return); all zero in the shipped build. */
-int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[8]);
+int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
 
 /* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host. */
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);

@@ -16,10 +16,11 @@ env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
 env.camera.max_depth = depth
 for _ in range(2):
     img = env.render((w, h))
-ph = (C.c_uint64 * 8)()
+ph = (C.c_uint64 * 16)()
 _capi.lib().eu_renderer_debug_phases(env.renderer(0), ph)
-tot = float(sum(ph)) or 1.0
-names = ["load ray+hit", "normal+exiting", "reflection ratio", "surface colour+threshold dir+material_at", "reflection dir+node writes", "background samples", "append+store children", "-"]
+tot = float(sum(ph[:8])) or 1.0
+names = ["load ray+hit", "normal+exiting", "reflection ratio", "surface colour+threshold dir+material_at", "reflection dir+node writes", "background samples", "append+store children", "-",
+         "  sub: surface_color", "  sub: to_pixel", "  sub: threshold_direction", "  sub: material_at", "-", "-", "-", "-"]
 print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"])
 for i, n in enumerate(names):
     print("  %-28s %6.2f%%  (%d cycles)" % (n, 100.0 * ph[i] / tot, ph[i]))
