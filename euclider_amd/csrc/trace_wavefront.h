@@ -305,7 +305,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
 
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
 template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
+__global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
                                                                   EuWfBuffers B, EuDevCounters *counters) {
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
