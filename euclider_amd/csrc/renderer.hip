@@ -151,7 +151,6 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
-        if (!r->scene_in_lds || h.hit_cap > 64) r->use_wavefront = false;   /* huge scenes: megakernel with the hit stack in scratch */
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
@@ -287,12 +286,15 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
-    if ((rc = wf_grid(r, eu_wf_intersect_kernel<D>, isect_lds, g_isect))) return rc;
+    const bool hs_lds = r->hit_cap <= 32;      /* else: private (scratch) hit stack of 96 entries */
+    if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
+    else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
     const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
     hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
     for (uint32_t g = 0; g < dc.max_depth; g++) {
-        hipLaunchKernelGGL(eu_wf_intersect_kernel<D>, dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
+        if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
+        else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, B, r->d_counters, hit_t);
         hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
     }
     for (uint32_t g = dc.max_depth; g-- > 0;)

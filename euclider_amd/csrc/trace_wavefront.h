@@ -30,6 +30,8 @@
 #ifndef EU_TRACE_WAVEFRONT_H
 #define EU_TRACE_WAVEFRONT_H
 
+#include <type_traits>
+
 #include "trace_device.h"
 
 #define EU_WF_BLOCK 256
@@ -254,14 +256,14 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
 }
 
 /* ------------------------------------------------------------------ trace_closest */
-template <int D>
+template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen,
                                                                       EuWfBuffers B, EuDevCounters *counters, double *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
-    S.init(scene_g);
-    HitStackLds HS;
-    {
+    S.init(scene_g);      /* wave-uniform addresses: the scene arrives through scalar loads */
+    typename std::conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
+    if constexpr (HSCAP == 0) {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         double *hs_t = (double *)(lds_dyn);
         uint32_t *hs_c = (uint32_t *)(hs_t + (EU_WF_BLOCK / 64) * hs_cap * 64);
