@@ -111,10 +111,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the trace path)")
+    # EU_BENCH_SMOKE_GLOO=1: rehearsal of the N > 1 control flow on a ONE-GPU box (all ranks on cuda:0, gather staged
+    # through the host with gloo).  Never used for reported numbers; the driver's multi-GPU runs use RCCL.
+    smoke_gloo = os.environ.get("EU_BENCH_SMOKE_GLOO") == "1"
+    if smoke_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if smoke_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
     env = Parser().parse_file(scene_path)
@@ -124,7 +132,7 @@ def main():
     frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
     local_rows = env.local_rows(frame)
     if world > 1:      # equal counts for the gather: pad to the largest rank
-        t = torch.tensor([local_rows], device=dev)
+        t = torch.tensor([local_rows], device=torch.device("cpu") if smoke_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         max_rows = int(t.item())
     else:
@@ -145,7 +153,16 @@ def main():
     def step():
         env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
         if world > 1:
-            dist.gather(rgba, gathered, dst=0)                      # the single RCCL gather
+            if smoke_gloo:                                          # one-GPU rehearsal only (see above)
+                torch.cuda.synchronize(dev)
+                host = rgba.cpu()
+                hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, hg, dst=0)
+                if rank == 0:
+                    for k in range(world):
+                        gathered[k].copy_(hg[k])
+            else:
+                dist.gather(rgba, gathered, dst=0)                  # the single RCCL gather
             if rank == 0:
                 torch.index_select(torch.cat(gathered, 0), 0, perm, out=full)
                 env.pack_rgb_device(full.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
@@ -153,6 +170,7 @@ def main():
             env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
 
     def sync():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -168,14 +186,18 @@ def main():
 
     st = env.stats(device=local_rank)
     kms = env.kernel_ms_history(min(args.steps, 64), device=local_rank)
-    tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rdev = torch.device("cpu") if smoke_gloo else dev
+    tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     rays_per_step = tot[0].item()
     elapsed = tmax.item()
 
+    if rank == 0 and os.environ.get("EU_BENCH_DUMP"):
+        import numpy as np
+        np.save(os.environ["EU_BENCH_DUMP"], rgb_out[:H * W * 3].cpu().numpy().reshape(H, W, 3))
     if rank == 0:
         value = rays_per_step * args.steps / elapsed / 1e6
         kernel_ms = sum(kms) / max(1, len(kms))

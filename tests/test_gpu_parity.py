@@ -104,3 +104,84 @@ def test_trace_screen_point_unquantised():
         q = [int(min(max(c, 0.0), 1.0) * 255.0) for c in rgb]
         assert q == list(img[y, x])
     env.close()
+
+
+@pytest.mark.parametrize("world,H", [(2, 90), (3, 100), (8, 64)])
+def test_strip_partition_matches_full_frame(world, H):
+    """The multi-GPU partition (8-row strips round-robin, eu_frame.strip_*) reassembles to the full frame."""
+    from euclider_amd import Parser, partition
+    env = Parser().parse_file(os.path.join(SCENES, "3d_room.json"))
+    env.camera.max_depth = 6
+    W = 160
+    full = env.render((W, H)).data
+    max_rows = max(partition.local_rows(H, r, world) for r in range(world))
+    bufs = []
+    for r in range(world):
+        part = env.render((W, H), strips=(r, world)).data
+        assert part.shape[0] == partition.local_rows(H, r, world)
+        pad = np.zeros((max_rows, W, 3), dtype=np.uint8)
+        pad[:part.shape[0]] = part
+        bufs.append(pad)
+    env.close()
+    cat = np.concatenate(bufs, axis=0)
+    perm = partition.gather_permutation(H, world, max_rows)
+    assert np.array_equal(cat[perm], full)
+
+
+def test_full_size_properties_config1():
+    """BASELINE.json configs[1] at its full size (3d_room, 1920x1080, depth 8), through size-independent properties:
+    idempotence, partition invariance (pixels and ray counts), and direct parity on sampled rows."""
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, "3d_room.json")
+    env = Parser().parse_file(path)
+    env.camera.max_depth = 8
+    W, H = 1920, 1080
+    a = env.render((W, H))
+    b = env.render((W, H))
+    assert np.array_equal(a.data, b.data) and a.stats == b.stats                       # idempotent
+    halves = [env.render((W, H), rows=(0, 536)), env.render((W, H), rows=(536, H))]
+    assert np.array_equal(np.concatenate([h.data for h in halves], 0), a.data)         # row tiles
+    assert sum(h.stats["rays"] for h in halves) == a.stats["rays"]
+    strips = [env.render((W, H), strips=(r, 2)) for r in range(2)]
+    assert sum(s.stats["rays"] for s in strips) == a.stats["rays"]                      # strip partition: a checksum of checksums
+    env.close()
+    osc = load_scene_file(path)
+    for y in (0, 333, 540, 541, 1079):                                                  # sampled rows against the oracle
+        rgb, _, _ = osc.render(W, H, max_depth=8, rows=(y, y + 1))
+        assert np.array_equal(rgb[0], a.data[y]), "row %d differs" % y
+
+
+@pytest.mark.parametrize("scene,depth", [("3d_hallways.json", 12), ("4d_frame.json", 8)])
+def test_full_size_sampled_rows_other_configs(scene, depth):
+    """configs[2] and configs[3] at 1920x1080: sampled rows against the oracle + partition invariance."""
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, scene)
+    env = Parser().parse_file(path)
+    env.camera.max_depth = depth
+    W, H = 1920, 1080
+    a = env.render((W, H))
+    parts = [env.render((W, H), rows=(0, 400)), env.render((W, H), rows=(400, H))]
+    assert np.array_equal(np.concatenate([p.data for p in parts], 0), a.data)
+    assert sum(p.stats["rays"] for p in parts) == a.stats["rays"]
+    env.close()
+    osc = load_scene_file(path)
+    for y in (7, 539, 540, 1000):
+        rgb, _, _ = osc.render(W, H, max_depth=depth, rows=(y, y + 1))
+        assert np.array_equal(rgb[0], a.data[y]), "row %d differs" % y
+
+
+def test_edge_cases():
+    from euclider_amd import Parser
+    env = Parser().parse_file(os.path.join(SCENES, "3d_fresnel.json"))
+    assert env.render((16, 16), rows=(5, 5)).data.shape == (0, 16, 3)                   # empty row range
+    one = env.render((1, 1))                                                            # 1x1 frame (odd size: axis-aligned ray)
+    assert one.data.shape == (1, 1, 3)
+    env.camera.max_depth = 0                                                            # depth 0: background only
+    bg = env.render((32, 32))
+    assert bg.stats["rays"] == 0 and bg.stats["bg_samples"] == 32 * 32
+    env.camera.max_depth = 16                                                           # compiled maximum
+    deep = env.render((32, 32))
+    assert deep.stats["rays"] > 32 * 32
+    env.close()

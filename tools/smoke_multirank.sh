@@ -1,0 +1,13 @@
+#!/bin/bash
+# Rehearsal of bench.py's N=2 control flow on a one-GPU box (gloo, both ranks on cuda:0) + check of the gathered frame
+# against a single-rank render of the same frame.  Diagnostic helper; not a measurement.
+set -e
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+W=2712; H=1528
+EU_BENCH_SMOKE_GLOO=1 EU_BENCH_DUMP=/tmp/eu_two.npy python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline | tail -1 | cut -c1-400
+EU_BENCH_DUMP=/tmp/eu_one.npy python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --width $W --height $H | tail -1 | cut -c1-200
+python - <<'PY'
+import numpy as np
+a=np.load("/tmp/eu_two.npy"); b=np.load("/tmp/eu_one.npy")
+print("two-rank frame == one-rank frame:", a.shape, b.shape, bool(np.array_equal(a,b)))
+PY
