@@ -286,14 +286,17 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
-    const bool hs_lds = r->hit_cap <= 32;      /* else: private (scratch) hit stack of 96 entries */
-    if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
+    const bool hs_lds = r->hit_cap <= 32 && !getenv("EU_HS_PRIVATE");      /* else: private (scratch) hit stack */
+    const bool hs_small = !hs_lds && r->hit_cap <= 16;
+    if (hs_small) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 16>, 0, g_isect))) return rc; }
+    else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
     const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
     hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
     for (uint32_t g = 0; g < dc.max_depth; g++) {
         if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
+        else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, B, r->d_counters, hit_t);
         else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, B, r->d_counters, hit_t);
         hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
     }
