@@ -748,6 +748,17 @@ struct Flattener {
             op.count = (uint8_t)chain.size();
             op.param = (uint32_t)params.size();
             for (auto *leaf : chain) push_halfspace_params(*leaf);
+            {   /* the chain's own bounding sphere (axis-aligned boxes only), right after its leaves: c[D], r2, far2; r2 < 0: none */
+                Bound b;
+                if (s.operation == SetOperation::Intersection) b = box_bound(chain);
+                double cmax = 0.0;
+                for (int i = 0; i < D; i++) cmax = std::max(cmax, fabs(b.c[i]));
+                const bool ok = b.ok && b.r > 0.0 && cmax <= 1.0e6 * b.r;
+                const double rr = b.r * (1.0 + 1.0e-6) + 1.0e-9 * std::max(1.0, cmax);
+                for (int i = 0; i < D; i++) params.push_back(ok ? b.c[i] : 0.0);
+                params.push_back(ok ? rr * rr : -1.0);
+                params.push_back(ok ? 1.0e8 * rr * rr : 0.0);
+            }
             n_leaves += (uint32_t)chain.size();
             len = (uint32_t)chain.size();
             uint32_t use = base_use + 2 * len;               /* the list + slots for the t_k (picked by run-time index) */

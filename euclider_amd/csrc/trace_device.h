@@ -360,6 +360,32 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
     return len;
 }
 
+/* Exact culling.  The loader gives every bounded entity (sphere, cuboid / hypercuboid, and Union /
+ * Intersection / Complement / SymmetricDifference trees over them) a bounding sphere enlarged by 1e-6.
+ * If the half-line o + d*t, t >= 0, stays outside it, no hit point of any leaf of the entity lies in the
+ * entity's shape: every hit point of a box chain violates one of the other half-spaces by a margin that
+ * dwarfs rounding (so the chain's hit stream is empty), a sphere's own discriminant is negative, and an
+ * operand that is not bounded only contributes points that fail the bounded operand's is_point_inside.
+ * The entity's stream is therefore empty and trace_closest would skip it anyway (universe/mod.rs:114):
+ * skipping the evaluation changes nothing.  The same test is applied to every box chain inside a CSG tree
+ * (its stream is empty, so an empty list is pushed without evaluating the chain).  NaN anywhere makes every comparison false: no culling. */
+template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o, const double *d) {
+    double rel[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) rel[i] = o[i] - Bd[i];
+    const double rr = vdot<D>(rel, rel);
+    const double cc = rr - Bd[D];
+    if (cc > 0.0) {                                   /* origin outside the enlarged sphere */
+        const double b = vdot<D>(d, rel);
+        if (b >= 0.0) return true;                    /* moving away: the closest point is the origin */
+        if (rr < Bd[D + 1]) {                         /* discriminant margin only holds for |o-c| < 1e4 R */
+            const double a = vdot<D>(d, d);
+            if (b * b - a * cc < 0.0) return true;    /* the whole line misses */
+        }
+    }
+    return false;
+}
+
 /* ------------------------------------------------------------------ CSG: eager post-order evaluation */
 /* Evaluates entity shape program ops[first..root] for ray (o, d); returns the number of hits of the
  * entity's stream and its first element (only that is used by trace_closest, universe/mod.rs:114). */
@@ -371,7 +397,10 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         S.op(root, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list;
-            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            const double *Pc = S.params(param);
+            const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
+            if (Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)) return 0u;
+            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, Pc, o, d, tk, list);
             if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
@@ -392,8 +421,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         S.op(i, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
+            const double *Pc = S.params(param);
+            const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
             if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
-            else n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, S.params(param), o, d, tk, list);
+            else if (!(Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)))
+                n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, Pc, o, d, tk, list);
             if (n) {
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
@@ -480,31 +512,6 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     const uint32_t n = (uint32_t)(lens & 0x7f);
     if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
     return n;
-}
-
-/* Exact culling.  The loader gives every bounded entity (sphere, cuboid / hypercuboid, and Union /
- * Intersection / Complement / SymmetricDifference trees over them) a bounding sphere enlarged by 1e-6.
- * If the half-line o + d*t, t >= 0, stays outside it, no hit point of any leaf of the entity lies in the
- * entity's shape: every hit point of a box chain violates one of the other half-spaces by a margin that
- * dwarfs rounding (so the chain's hit stream is empty), a sphere's own discriminant is negative, and an
- * operand that is not bounded only contributes points that fail the bounded operand's is_point_inside.
- * The entity's stream is therefore empty and trace_closest would skip it anyway (universe/mod.rs:114):
- * skipping the evaluation changes nothing.  NaN anywhere makes every comparison false: no culling. */
-template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o, const double *d) {
-    double rel[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) rel[i] = o[i] - Bd[i];
-    const double rr = vdot<D>(rel, rel);
-    const double cc = rr - Bd[D];
-    if (cc > 0.0) {                                   /* origin outside the enlarged sphere */
-        const double b = vdot<D>(d, rel);
-        if (b >= 0.0) return true;                    /* moving away: the closest point is the origin */
-        if (rr < Bd[D + 1]) {                         /* discriminant margin only holds for |o-c| < 1e4 R */
-            const double a = vdot<D>(d, d);
-            if (b * b - a * cc < 0.0) return true;    /* the whole line misses */
-        }
-    }
-    return false;
 }
 
 /* normal of the hit described by `code` at parameter t (recomputed from the leaf) */
