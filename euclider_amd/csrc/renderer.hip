@@ -282,7 +282,6 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     if (rc != EU_OK) return rc;
     EuWfBuffers B = r->wf;
     B.npix = df.single_pixel ? 1u : (uint32_t)pixels;
-    const size_t scene_bytes = (size_t)r->scene_words * 8;
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
@@ -293,7 +292,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
     const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
-    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), scene_bytes, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
+    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
     for (uint32_t g = 0; g < dc.max_depth; g++) {
         if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
         else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, B, r->d_counters, hit_t);

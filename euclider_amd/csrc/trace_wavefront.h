@@ -96,12 +96,6 @@ EU_DEV uint32_t wf_append_local(uint32_t *lds_counter, uint32_t n /* 0..2 slots 
     return base + rank1;
 }
 
-EU_DEV const uint64_t *wf_stage_scene(const uint64_t *scene_g, uint32_t scene_words, uint64_t *lds) {
-    for (uint32_t i = threadIdx.x; i < scene_words; i += blockDim.x) lds[i] = scene_g[i];
-    __syncthreads();
-    return lds;
-}
-
 /* Balanced consumption of a segmented queue: every workgroup scans the (<= 1024) segment lengths of
  * the generation into LDS; the rays then form one virtual index space that is dealt out grid-stride,
  * and a lane maps its virtual index back to (segment, offset) with a binary search in LDS. */
@@ -164,7 +158,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
     EuScene S;
-    S.init(wf_stage_scene(scene_g, scene_words, lds_dyn));
+    S.init(scene_g);
     LaneCounters cnt = {0, 0, 0, 0};
     const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;
     const uint32_t rows = fr.local_rows;

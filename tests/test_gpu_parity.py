@@ -185,3 +185,21 @@ def test_edge_cases():
     deep = env.render((32, 32))
     assert deep.stats["rays"] > 32 * 32
     env.close()
+
+
+def test_megakernel_variant_matches_wavefront(monkeypatch):
+    """The persistent megakernel (EU_KERNEL=mega, kept for A/B) and the wavefront pipeline give the same frame."""
+    from euclider_amd import Parser
+    path = os.path.join(SCENES, "3d_room.json")
+    a = Parser().parse_file(path)
+    a.camera.max_depth = 6
+    wf = a.render((200, 120), want_hit_t=True)
+    a.close()
+    monkeypatch.setenv("EU_KERNEL", "mega")
+    b = Parser().parse_file(path)
+    b.camera.max_depth = 6
+    mk = b.render((200, 120), want_hit_t=True)
+    b.close()
+    assert np.array_equal(wf.data, mk.data)
+    assert np.array_equal(wf.hit_t, mk.hit_t, equal_nan=True)
+    assert wf.stats["rays"] == mk.stats["rays"] and wf.stats["bg_samples"] == mk.stats["bg_samples"]
