@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-frame", action="store_true", help="keep width x height for every N (strong scaling, e.g. BASELINE config 5: 7680x4320 on 8 GPUs)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
     return ap.parse_args()
 
@@ -127,7 +128,7 @@ def main():
     scene_path = os.path.join(ROOT, "scenes", args.scene)
     env = Parser().parse_file(scene_path)
     env.camera.max_depth = args.max_depth
-    W, H = frame_dims(args.width, args.height, world)
+    W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
     strips = (rank, world) if world > 1 else None
     frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
     local_rows = env.local_rows(frame)
@@ -209,7 +210,7 @@ def main():
         out = {
             "metric": "Mray/s (primary+secondary) at 1920x1080 depth-8; frac of HBM roofline",
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.fixed_frame else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,

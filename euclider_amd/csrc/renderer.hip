@@ -92,6 +92,7 @@ struct eu_renderer {
     EuWfBuffers wf{};
     size_t wf_pixels = 0;
     double wf_ray_factor = 4.0;
+    uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass (EU_WF_BAND_PIXELS) */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -151,6 +152,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
+        if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
@@ -276,12 +278,19 @@ template <class K> static int wf_grid(eu_renderer *r, K kern, size_t lds_bytes, 
 }
 
 template <int D>
-static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
-    const size_t pixels = (size_t)df.local_rows * df.width;
-    int rc = wf_ensure(r, df.single_pixel ? 64 : pixels);
+static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
+    /* Large frames are traced in bands of whole 8-row tiles so that the queue and node buffers stay bounded
+     * (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes). */
+    uint32_t band_rows = df_in.local_rows;
+    if (!df_in.single_pixel) {
+        uint64_t rows_fit = r->wf_band_pixels / (df_in.width ? df_in.width : 1);
+        rows_fit = rows_fit / 8 * 8;
+        if (rows_fit < 8) rows_fit = 8;
+        if (rows_fit < band_rows) band_rows = (uint32_t)rows_fit;
+    }
+    const size_t band_pixels = (size_t)band_rows * df_in.width;
+    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels);
     if (rc != EU_OK) return rc;
-    EuWfBuffers B = r->wf;
-    B.npix = df.single_pixel ? 1u : (uint32_t)pixels;
     const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
@@ -291,19 +300,32 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
-    const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
-    hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
-    for (uint32_t g = 0; g < dc.max_depth; g++) {
-        if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, B, r->d_counters, hit_t);
-        else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, B, r->d_counters, hit_t);
-        else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, B, r->d_counters, hit_t);
-        hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+    for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows) {
+        EuDevFrame df = df_in;
+        EuWfBuffers B = r->wf;
+        if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; B.npix = 1u; }
+        else {
+            df.band_row0 = row0;
+            df.band_rows = df_in.local_rows - row0 < band_rows ? df_in.local_rows - row0 : band_rows;
+            df.root_base = row0 * df.width;
+            df.n_tiles = df.tiles_x * ((df.band_rows + 7) / 8);
+            B.npix = df.band_rows * df.width;
+        }
+        const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
+        hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
+        for (uint32_t g = 0; g < dc.max_depth; g++) {
+            if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
+            else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
+            else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
+            hipLaunchKernelGGL(eu_wf_shade_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+        }
+        for (uint32_t g = dc.max_depth; g-- > 0;)
+            hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);
+        unsigned gf = (unsigned)((B.npix + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
+        if (gf > (unsigned)r->num_cus * 16u) gf = (unsigned)r->num_cus * 16u;
+        hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, df.root_base, r->d_counters, rgba, point);
+        if (df.single_pixel) break;
     }
-    for (uint32_t g = dc.max_depth; g-- > 0;)
-        hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);
-    unsigned gf = (unsigned)((B.npix + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
-    if (gf > (unsigned)r->num_cus * 16u) gf = (unsigned)r->num_cus * 16u;
-    hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, r->d_counters, rgba, point);
     HIP_TRY(hipGetLastError());
     return EU_OK;
 }

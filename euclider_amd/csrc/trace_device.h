@@ -46,6 +46,7 @@ struct EuDevFrame {
     uint32_t tiles_x, n_tiles, debug_crosshair, single_pixel;
     uint32_t single_x, single_y;
     uint32_t local_rows, strip_count, strip_index, pad;   /* rows in the output buffer; interleaved-strip partition */
+    uint32_t band_row0, band_rows, root_base, pad2;        /* wavefront: the band of local rows traced by this pass; root_base = band_row0 * width */
     double time_s;          /* time_millis, d3/entity/surface.rs:32 */
 };
 

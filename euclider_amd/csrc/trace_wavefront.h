@@ -184,8 +184,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
             } else {
                 const uint32_t tile = (uint32_t)(item >> 6), within = (uint32_t)(item & 63);   /* 8x8 pixel tiles: coherent waves */
                 px_x = (tile % fr.tiles_x) * 8 + (within & 7);
-                ry = (tile / fr.tiles_x) * 8 + (within >> 3);
-                if (px_x >= fr.width || ry >= rows) break;
+                ry = fr.band_row0 + (tile / fr.tiles_x) * 8 + (within >> 3);
+                if (px_x >= fr.width || ry >= rows || ry >= fr.band_row0 + fr.band_rows) break;
                 out_idx = ry * fr.width + px_x;
                 if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
                     const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
@@ -193,12 +193,12 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                     if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
                         rgba[out_idx] = 0u;
                         if (hit_t) hit_t[out_idx] = -1.0;
-                        B.node_meta[out_idx] = WF_NONE;
+                        B.node_meta[out_idx - fr.root_base] = WF_NONE;
                         break;
                     }
                 } else px_y = fr.row_begin + ry;
             }
-            B.node_meta[out_idx] = WF_NONE;
+            B.node_meta[out_idx - fr.root_base] = WF_NONE;
             if (hit_t) hit_t[out_idx] = -1.0;
             /* Environment::render's cross-hair (universe/mod.rs:321-333) */
             const uint32_t hw = fr.width / 2, hh = fr.height / 2;
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                 break;
             }
             material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
-            B.node_meta[out_idx] = WF_ROOT;
+            B.node_meta[out_idx - fr.root_base] = WF_ROOT;
             if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
-                wf_deliver(B, out_idx, 0, wf_background<D>(S, d, cnt));
+                wf_deliver(B, out_idx - fr.root_base, 0, wf_background<D>(S, d, cnt));
                 break;
             }
             ent_u = (uint32_t)ent;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
         const uint32_t pos = wf_append_local(&seg_fill, have_ray ? 1u : 0u, second);
         if (have_ray) {
             if (pos >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
-            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx, ent_u);
+            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx - fr.root_base, ent_u);
         }
     }
     __syncthreads();
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
 
 /* ------------------------------------------------------------------ trace_closest */
 template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen,
+__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
                                                                       EuWfBuffers B, EuDevCounters *counters, double *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;
             B.hit_ent[i] = best_ent;
-            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -1.0;
+            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i] + root_base] = have ? best_t : -1.0;
         }
     }
     wf_flush_counters(counters, cnt);
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen
 }
 
 /* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_final_kernel(EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
+__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_final_kernel(EuWfBuffers B, uint32_t root_base, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
     LaneCounters cnt = {0, 0, 0, 0};
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
         if ((B.node_meta[p] & 0xffu) != WF_ROOT) continue;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_final_kernel(EuWfBuffers B,
         const Rgba ret = {ch[0], ch[1], ch[2], ch[3]};
         const Rgba white = {1.0, 1.0, 1.0, 1.0};
         const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(ret), into_premultiplied(white)));
-        rgba[p] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
+        rgba[p + root_base] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
         if (point_rgb) { point_rgb[0] = out.r; point_rgb[1] = out.g; point_rgb[2] = out.b; }
     }
     wf_flush_counters(counters, cnt);

@@ -203,3 +203,22 @@ def test_megakernel_variant_matches_wavefront(monkeypatch):
     assert np.array_equal(wf.data, mk.data)
     assert np.array_equal(wf.hit_t, mk.hit_t, equal_nan=True)
     assert wf.stats["rays"] == mk.stats["rays"] and wf.stats["bg_samples"] == mk.stats["bg_samples"]
+
+
+def test_banded_wavefront_matches_single_pass(monkeypatch):
+    """Frames larger than the wavefront band size are traced in several passes; the result must not change."""
+    from euclider_amd import Parser
+    path = os.path.join(SCENES, "3d_room.json")
+    a = Parser().parse_file(path)
+    a.camera.max_depth = 6
+    one = a.render((320, 200), want_hit_t=True)
+    a.close()
+    monkeypatch.setenv("EU_WF_BAND_PIXELS", str(320 * 24))          # 24-row bands -> 9 passes
+    b = Parser().parse_file(path)
+    b.camera.max_depth = 6
+    many = b.render((320, 200), want_hit_t=True)
+    strips = b.render((320, 200), strips=(1, 3))
+    b.close()
+    assert np.array_equal(one.data, many.data) and np.array_equal(one.hit_t, many.hit_t, equal_nan=True)
+    assert one.stats == many.stats
+    assert strips.data.shape[0] > 0
