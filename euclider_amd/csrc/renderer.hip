@@ -89,10 +89,13 @@ struct eu_renderer {
     bool scene_in_lds = true;
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
     bool use_wavefront = true;
-    EuWfBuffers wf{};
+    EuWfBuffers wf[2] = {};                  /* two band pipelines run concurrently on two side streams */
     size_t wf_pixels = 0;
+    hipStream_t wf_stream[2] = {nullptr, nullptr};
+    hipEvent_t wf_fork = nullptr, wf_join[2] = {nullptr, nullptr};
     double wf_ray_factor = 4.0;
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass (EU_WF_BAND_PIXELS) */
+    bool wf_two_streams = true;              /* EU_WF_STREAMS=1 disables */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -153,6 +156,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
+        if (const char *k = getenv("EU_WF_STREAMS")) r->wf_two_streams = atoi(k) != 1;
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
@@ -172,6 +176,8 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     (void)hipSetDevice(r->device);
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) { if (r->wf_stream[k]) (void)hipStreamDestroy(r->wf_stream[k]); if (r->wf_join[k]) (void)hipEventDestroy(r->wf_join[k]); }
+    if (r->wf_fork) (void)hipEventDestroy(r->wf_fork);
     if (r->d_scene) (void)hipFree(r->d_scene);
     if (r->d_counters) (void)hipFree(r->d_counters);
     if (r->d_rgba) (void)hipFree(r->d_rgba);
@@ -230,7 +236,8 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     r->wf_allocs.clear();
     r->wf_pixels = 0;
     const int D = r->dim;
-    EuWfBuffers &B = r->wf;
+    for (int set = 0; set < 2; set++) {
+    EuWfBuffers &B = r->wf[set];
     memset(&B, 0, sizeof B);
     /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
     uint32_t n_seg = (uint32_t)r->num_cus * 3u;
@@ -265,6 +272,11 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     if ((rc = alloc((void **)&B.seg_count, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4))) return rc;
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
+    }
+    if (!r->wf_stream[0]) {
+        for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamCreateWithFlags(&r->wf_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&r->wf_join[k], hipEventDisableTiming)); }
+        HIP_TRY(hipEventCreateWithFlags(&r->wf_fork, hipEventDisableTiming));
+    }
     r->wf_pixels = pixels;
     return EU_OK;
 }
@@ -278,15 +290,23 @@ template <class K> static int wf_grid(eu_renderer *r, K kern, size_t lds_bytes, 
 }
 
 template <int D>
-static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
+static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
     /* Large frames are traced in bands of whole 8-row tiles so that the queue and node buffers stay bounded
      * (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes). */
     uint32_t band_rows = df_in.local_rows;
+    bool two_streams = false;
     if (!df_in.single_pixel) {
         uint64_t rows_fit = r->wf_band_pixels / (df_in.width ? df_in.width : 1);
         rows_fit = rows_fit / 8 * 8;
         if (rows_fit < 8) rows_fit = 8;
         if (rows_fit < band_rows) band_rows = (uint32_t)rows_fit;
+        /* at least two bands for anything but tiny frames: they run on two streams, so the tail and the launch gap
+         * of one band's kernel are filled by the other band's kernel */
+        if ((uint64_t)df_in.local_rows * df_in.width >= (1u << 19) && r->wf_two_streams) {
+            const uint32_t half = (((df_in.local_rows + 1) / 2) + 7) / 8 * 8;
+            if (half < band_rows) band_rows = half;
+            two_streams = true;
+        }
     }
     const size_t band_pixels = (size_t)band_rows * df_in.width;
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels);
@@ -300,9 +320,16 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
-    for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows) {
+    if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
+        HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
+        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
+    }
+    uint32_t band_no = 0;
+    for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows, band_no++) {
         EuDevFrame df = df_in;
-        EuWfBuffers B = r->wf;
+        const int set = two_streams ? (int)(band_no & 1u) : 0;
+        hipStream_t stream = two_streams ? r->wf_stream[set] : caller_stream;
+        EuWfBuffers B = r->wf[set];
         if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; B.npix = 1u; }
         else {
             df.band_row0 = row0;
@@ -325,6 +352,9 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera
         if (gf > (unsigned)r->num_cus * 16u) gf = (unsigned)r->num_cus * 16u;
         hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, df.root_base, r->d_counters, rgba, point);
         if (df.single_pixel) break;
+    }
+    if (two_streams) {      /* join */
+        for (int k = 0; k < 2; k++) { HIP_TRY(hipEventRecord(r->wf_join[k], r->wf_stream[k])); HIP_TRY(hipStreamWaitEvent(caller_stream, r->wf_join[k], 0)); }
     }
     HIP_TRY(hipGetLastError());
     return EU_OK;
