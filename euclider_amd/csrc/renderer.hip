@@ -89,13 +89,14 @@ struct eu_renderer {
     bool scene_in_lds = true;
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
     bool use_wavefront = true;
-    EuWfBuffers wf[2] = {};                  /* two band pipelines run concurrently on two side streams */
+    static constexpr int WF_MAX_STREAMS = 4;
+    EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
-    hipStream_t wf_stream[2] = {nullptr, nullptr};
-    hipEvent_t wf_fork = nullptr, wf_join[2] = {nullptr, nullptr};
+    hipStream_t wf_stream[WF_MAX_STREAMS] = {};
+    hipEvent_t wf_fork = nullptr, wf_join[WF_MAX_STREAMS] = {};
+    int wf_n_streams = 2;                    /* EU_WF_STREAMS (1 = everything on the caller's stream) */
     double wf_ray_factor = 4.0;
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass (EU_WF_BAND_PIXELS) */
-    bool wf_two_streams = true;              /* EU_WF_STREAMS=1 disables */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -156,7 +157,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
-        if (const char *k = getenv("EU_WF_STREAMS")) r->wf_two_streams = atoi(k) != 1;
+        if (const char *k = getenv("EU_WF_STREAMS")) { int v = atoi(k); r->wf_n_streams = v < 1 ? 1 : (v > eu_renderer::WF_MAX_STREAMS ? eu_renderer::WF_MAX_STREAMS : v); }
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
@@ -176,7 +177,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     (void)hipSetDevice(r->device);
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
-    for (int k = 0; k < 2; k++) { if (r->wf_stream[k]) (void)hipStreamDestroy(r->wf_stream[k]); if (r->wf_join[k]) (void)hipEventDestroy(r->wf_join[k]); }
+    for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { if (r->wf_stream[k]) (void)hipStreamDestroy(r->wf_stream[k]); if (r->wf_join[k]) (void)hipEventDestroy(r->wf_join[k]); }
     if (r->wf_fork) (void)hipEventDestroy(r->wf_fork);
     if (r->d_scene) (void)hipFree(r->d_scene);
     if (r->d_counters) (void)hipFree(r->d_counters);
@@ -236,7 +237,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     r->wf_allocs.clear();
     r->wf_pixels = 0;
     const int D = r->dim;
-    for (int set = 0; set < 2; set++) {
+    for (int set = 0; set < r->wf_n_streams; set++) {
     EuWfBuffers &B = r->wf[set];
     memset(&B, 0, sizeof B);
     /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
@@ -274,7 +275,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
     }
     if (!r->wf_stream[0]) {
-        for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamCreateWithFlags(&r->wf_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&r->wf_join[k], hipEventDisableTiming)); }
+        for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { HIP_TRY(hipStreamCreateWithFlags(&r->wf_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&r->wf_join[k], hipEventDisableTiming)); }
         HIP_TRY(hipEventCreateWithFlags(&r->wf_fork, hipEventDisableTiming));
     }
     r->wf_pixels = pixels;
@@ -302,9 +303,10 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         if (rows_fit < band_rows) band_rows = (uint32_t)rows_fit;
         /* at least two bands for anything but tiny frames: they run on two streams, so the tail and the launch gap
          * of one band's kernel are filled by the other band's kernel */
-        if ((uint64_t)df_in.local_rows * df_in.width >= (1u << 19) && r->wf_two_streams) {
-            const uint32_t half = (((df_in.local_rows + 1) / 2) + 7) / 8 * 8;
-            if (half < band_rows) band_rows = half;
+        if ((uint64_t)df_in.local_rows * df_in.width >= (1u << 19) && r->wf_n_streams > 1) {
+            const uint32_t ns = (uint32_t)r->wf_n_streams;
+            const uint32_t part = (((df_in.local_rows + ns - 1) / ns) + 7) / 8 * 8;
+            if (part < band_rows) band_rows = part;
             two_streams = true;
         }
     }
@@ -322,12 +324,12 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
     if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
-        for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
+        for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
     }
     uint32_t band_no = 0;
     for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows, band_no++) {
         EuDevFrame df = df_in;
-        const int set = two_streams ? (int)(band_no & 1u) : 0;
+        const int set = two_streams ? (int)(band_no % (uint32_t)r->wf_n_streams) : 0;
         hipStream_t stream = two_streams ? r->wf_stream[set] : caller_stream;
         EuWfBuffers B = r->wf[set];
         if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; B.npix = 1u; }
@@ -354,7 +356,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         if (df.single_pixel) break;
     }
     if (two_streams) {      /* join */
-        for (int k = 0; k < 2; k++) { HIP_TRY(hipEventRecord(r->wf_join[k], r->wf_stream[k])); HIP_TRY(hipStreamWaitEvent(caller_stream, r->wf_join[k], 0)); }
+        for (int k = 0; k < r->wf_n_streams; k++) { HIP_TRY(hipEventRecord(r->wf_join[k], r->wf_stream[k])); HIP_TRY(hipStreamWaitEvent(caller_stream, r->wf_join[k], 0)); }
     }
     HIP_TRY(hipGetLastError());
     return EU_OK;
