@@ -1057,6 +1057,10 @@ FlatScene flatten(const Universe &u) {
     h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
     h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * 8);
     h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
+    /* flags bit 0: some surface can spawn BOTH a transmission and a reflection ray (ratio strictly between 0 and 1
+     * possible): the recursion tree branches and a frame holds several times more rays than pixels */
+    for (auto &fs : f.surfaces)
+        if (fs.ratio_kind == EU_RATIO_FRESNEL || (fs.ratio_p0 > 0.0 && fs.ratio_p0 < 1.0)) h.flags |= 1u;
     h.n_words = (uint32_t)w.size();
     memcpy(w.data(), &h, sizeof h);
     out.textures = f.textures;
