@@ -2,7 +2,7 @@
 """bench.py -- Mray/s of the per-pixel trace loop on MI355X (BASELINE.json metric).
 
 One "step" = one Environment::render pass: every pixel of the frame is traced by the HIP
-persistent-wavefront kernel (scene, textures and the output frame resident in HBM) and the
+wavefront pipeline (gen, intersect+shade per generation, resolve, final; scene, textures and the output frame resident in HBM) and the
 RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
 
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
