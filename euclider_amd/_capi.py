@@ -16,10 +16,16 @@ EU_ERR_NO_DEVICE = -3
 EU_ERR_HIP = -4
 EU_ERR_CAPACITY = -5
 EU_ERR_TEXTURE = -6
+EU_ERR_UNIMPLEMENTED = -7
+EU_ERR_PATH_STEPS = -8
+
+EU_CAMERA_PITCH_YAW_3, EU_CAMERA_FREE_3, EU_CAMERA_FREE_4 = 0, 1, 2
+KEYS = {name: 1 << i for i, name in enumerate(
+    ["W", "S", "A", "D", "LShift", "LControl", "Q", "E", "C", "M", "I", "O", "K", "L"])}
 
 
 class Camera(C.Structure):
-    _fields_ = [("dim", C.c_int32), ("fov_deg", C.c_uint32), ("max_depth", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("dim", C.c_int32), ("fov_deg", C.c_uint32), ("max_depth", C.c_uint32), ("kind", C.c_uint32),
                 ("location", C.c_double * 4), ("forward", C.c_double * 4), ("up", C.c_double * 4),
                 ("left", C.c_double * 4)]
 
@@ -28,6 +34,12 @@ class Frame(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("time_ms", C.c_uint64), ("debug_crosshair", C.c_int32), ("strip_count", C.c_uint32),
                 ("strip_index", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Input(C.Structure):
+    _fields_ = [("keys", C.c_uint32), ("delta_mouse_x", C.c_int32), ("delta_mouse_y", C.c_int32),
+                ("reserved", C.c_uint32), ("delta_time_ms", C.c_uint64), ("mouse_sensitivity", C.c_double),
+                ("speed", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -75,6 +87,9 @@ SYMBOLS = {
                             C.POINTER(Stats)]),
     "eu_trace_screen_point": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_int32, C.c_int32,
                                          C.POINTER(C.c_double)]),
+    "eu_trace_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "eu_camera_update": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Input)]),
     "eu_selftest_math": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "eu_version": (C.c_char_p, []),
 }

@@ -30,6 +30,8 @@
 #include "trace_device.h"
 #include "trace_megakernel.h"
 #include "trace_wavefront.h"
+#include "trace_path.h"
+#include "camera_host.hpp"
 
 /* RGBA8 -> packed RGB8 (RawImage2d U8U8U8, universe/mod.rs:351-356): 4 pixels (16 B in, 12 B out) per thread */
 __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *__restrict__ rgb, size_t pixels) {
@@ -80,6 +82,8 @@ struct eu_renderer {
     uint8_t *d_rgb = nullptr;
     double *d_hit = nullptr;
     double *d_point = nullptr;
+    double *d_path_in = nullptr;            /* eu_trace_path: location, direction, distance */
+    EuPathResult *d_path_out = nullptr;
     static constexpr int EV_RING = 64;        /* per-launch HIP event pairs, on the launch stream */
     hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {};
     unsigned long long launches = 0;
@@ -186,6 +190,8 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (r->d_rgb) (void)hipFree(r->d_rgb);
     if (r->d_hit) (void)hipFree(r->d_hit);
     if (r->d_point) (void)hipFree(r->d_point);
+    if (r->d_path_in) (void)hipFree(r->d_path_in);
+    if (r->d_path_out) (void)hipFree(r->d_path_out);
     for (int i = 0; i < eu_renderer::EV_RING; i++) { if (r->ev_start[i]) (void)hipEventDestroy(r->ev_start[i]); if (r->ev_stop[i]) (void)hipEventDestroy(r->ev_stop[i]); }
     delete r;
 }
@@ -522,6 +528,48 @@ extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const
     if (rc != EU_OK) return rc;
     HIP_TRY(hipMemcpy(rgb, r->d_point, 3 * sizeof(double), hipMemcpyDeviceToHost));
     return EU_OK;
+}
+
+/* Universe::trace_path_unknown (universe/mod.rs:273-286) on the resident scene: one lane, synchronous. */
+extern "C" int eu_trace_path(eu_renderer *r, const double location[4], const double direction[4], double distance,
+                             double out_location[4], double out_direction[4], int32_t *found) {
+    if (!r || !location || !direction || !out_location || !out_direction || !found) return EU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->hit_cap > 96) { r->err = "scene needs a deeper hit stack than the path kernel has (96)"; return EU_ERR_CAPACITY; }
+    if (!r->d_path_in) {
+        HIP_TRY(hipMalloc((void **)&r->d_path_in, 9 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&r->d_path_out, sizeof(EuPathResult)));
+    }
+    const int D = r->dim;
+    double in[9];
+    for (int k = 0; k < D; k++) { in[k] = location[k]; in[D + k] = direction[k]; }
+    in[2 * D] = distance;
+    HIP_TRY(hipMemcpy(r->d_path_in, in, sizeof in, hipMemcpyHostToDevice));
+    if (D == 3) hipLaunchKernelGGL(eu_trace_path_kernel<3>, dim3(1), dim3(64), 0, nullptr, r->d_scene, r->d_path_in, r->d_path_out);
+    else hipLaunchKernelGGL(eu_trace_path_kernel<4>, dim3(1), dim3(64), 0, nullptr, r->d_scene, r->d_path_in, r->d_path_out);
+    HIP_TRY(hipGetLastError());
+    EuPathResult res;
+    HIP_TRY(hipMemcpy(&res, r->d_path_out, sizeof res, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) { out_location[k] = k < D ? res.location[k] : 0.0; out_direction[k] = k < D ? res.direction[k] : 0.0; }
+    if (res.found < 0) { *found = 0; r->err = "trace_path: more than 4096 surface crossings"; return EU_ERR_PATH_STEPS; }
+    *found = res.found;
+    return EU_OK;
+}
+
+/* Camera::update (Environment::update, universe/mod.rs:399-405): rotation on the host (camera_host.cpp),
+ * translation through eu_trace_path. */
+extern "C" int eu_camera_update(eu_renderer *r, eu_camera *cam, const eu_input *in) {
+    if (!cam || !in) return EU_ERR_INVALID_ARGUMENT;
+    if (r && cam->dim != r->dim) { r->err = "camera dimension does not match the scene"; return EU_ERR_INVALID_ARGUMENT; }
+    euclider::TracePathFn fn;
+    if (r) fn = [r](const double *loc, const double *dir, double dist, double *ol, double *od) -> int {
+        double l4[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0};
+        for (int k = 0; k < r->dim; k++) { l4[k] = loc[k]; d4[k] = dir[k]; }
+        int32_t found = 0;
+        const int rc = eu_trace_path(r, l4, d4, dist, ol, od, &found);
+        return rc != EU_OK ? rc : (int)found;
+    };
+    return euclider::camera_update(cam, in, fn);
 }
 
 extern "C" int eu_selftest_math(int device, int fn, const double *x, const double *y, double *out, size_t n) {

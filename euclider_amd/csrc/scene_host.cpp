@@ -663,14 +663,21 @@ void Parser_::build_registry() {
                  u->background = as<MappedTexture>(a[2]);
                  return wrap(u);
              });
-        auto cam0 = [d](Parser_ &, std::vector<Value> &) { return wrap(std::make_shared<eu_camera>(default_camera(d, nullptr))); };
-        auto cam1 = [d](Parser_ &, std::vector<Value> &a) { return wrap(std::make_shared<eu_camera>(default_camera(d, vp(a[0])))); };
-        if (d == 3) {
-            addn({"PitchYawCamera3", "PitchYawCamera3::new", "FreeCamera3", "FreeCamera3::new"}, {}, ty(T::Camera, 3), cam0);
-            addn({"PitchYawCamera3::new_with_location", "FreeCamera3::new_with_location"}, {{"location", P}}, ty(T::Camera, 3), cam1);
+        auto camk = [d](uint32_t kind, bool with_loc) {
+            return [d, kind, with_loc](Parser_ &, std::vector<Value> &a) {
+                auto c = std::make_shared<eu_camera>(default_camera(d, with_loc ? vp(a[0]) : nullptr));
+                c->kind = kind;
+                return wrap(c);
+            };
+        };
+        if (d == 3) {      /* scene.rs:1353-1391 */
+            addn({"PitchYawCamera3", "PitchYawCamera3::new"}, {}, ty(T::Camera, 3), camk(EU_CAMERA_PITCH_YAW_3, false));
+            addn({"PitchYawCamera3::new_with_location"}, {{"location", P}}, ty(T::Camera, 3), camk(EU_CAMERA_PITCH_YAW_3, true));
+            addn({"FreeCamera3", "FreeCamera3::new"}, {}, ty(T::Camera, 3), camk(EU_CAMERA_FREE_3, false));
+            addn({"FreeCamera3::new_with_location"}, {{"location", P}}, ty(T::Camera, 3), camk(EU_CAMERA_FREE_3, true));
         } else {
-            addn({"FreeCamera4", "FreeCamera4::new"}, {}, ty(T::Camera, 4), cam0);
-            addn({"FreeCamera4::new_with_location"}, {{"location", P}}, ty(T::Camera, 4), cam1);
+            addn({"FreeCamera4", "FreeCamera4::new"}, {}, ty(T::Camera, 4), camk(EU_CAMERA_FREE_4, false));
+            addn({"FreeCamera4::new_with_location"}, {{"location", P}}, ty(T::Camera, 4), camk(EU_CAMERA_FREE_4, true));
         }
     }
 }

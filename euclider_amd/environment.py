@@ -35,9 +35,14 @@ class EuError(RuntimeError):
 class SimulationContext:
     """simulation.rs:167-186 (the fields render() reads)."""
 
-    def __init__(self, resolution=1, debugging=False):
+    def __init__(self, resolution=1, debugging=False, pressed_keys=(), delta_mouse=(0, 0)):
         self.resolution = resolution
         self.debugging = debugging
+        self.pressed_keys = set(pressed_keys)      # names of glutin VirtualKeyCode: "W", "S", "A", "D", "LShift", ...
+        self.delta_mouse = tuple(delta_mouse)
+
+    def key_mask(self):
+        return sum(_capi.KEYS[k] for k in self.pressed_keys)
 
 
 class RawImage2d:
@@ -117,6 +122,28 @@ class Environment:
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return tuple(rgb)
+
+    def trace_path_unknown(self, distance, location, direction, device=0):
+        """Universe::trace_path_unknown (universe/mod.rs:273-286) -> (location, direction) or None.  Runs on the GPU."""
+        D = self.dim
+        loc = (C.c_double * 4)(*([float(x) for x in location] + [0.0] * (4 - D)))
+        dr = (C.c_double * 4)(*([float(x) for x in direction] + [0.0] * (4 - D)))
+        ol, od, found = (C.c_double * 4)(), (C.c_double * 4)(), C.c_int32(0)
+        rc = _capi.lib().eu_trace_path(self.renderer(device), loc, dr, float(distance), ol, od, C.byref(found))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return (tuple(ol)[:D], tuple(od)[:D]) if found.value else None
+
+    def update(self, delta_time, context=None, device=0, mouse_sensitivity=0.0, speed=0.0):
+        """Environment::update (universe/mod.rs:359,399-405): Camera::update with the context's keys and mouse delta.
+        Mutates self.camera.  Raises EuError(EU_ERR_UNIMPLEMENTED) where the reference panics with unimplemented!()."""
+        context = context or SimulationContext()
+        inp = _capi.Input(context.key_mask(), int(context.delta_mouse[0]), int(context.delta_mouse[1]), 0,
+                          _duration_to_ms(delta_time), mouse_sensitivity, speed)
+        moves = inp.delta_time_ms != 0 and (inp.keys & (0xff if self.dim == 4 else 0x3f)) != 0
+        rc = _capi.lib().eu_camera_update(self.renderer(device) if moves else None, C.byref(self.camera), C.byref(inp))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
 
     def render(self, dimensions, time=0.0, threads=0, context=None, device=0, want_hit_t=False, rows=None, strips=None):
         """Environment::render.  `threads` is accepted for signature parity and ignored (the GPU

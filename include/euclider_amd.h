@@ -33,6 +33,8 @@ extern "C" {
 #define EU_ERR_HIP (-4)
 #define EU_ERR_CAPACITY (-5)       /* scene exceeds a compiled-in kernel capacity */
 #define EU_ERR_TEXTURE (-6)
+#define EU_ERR_UNIMPLEMENTED (-7)  /* the reference reaches `unimplemented!()` here (d4/entity/camera.rs:234) */
+#define EU_ERR_PATH_STEPS (-8)     /* eu_trace_path: more than 4096 surface crossings in one call */
 
 typedef struct eu_scene eu_scene;        /* a parsed + flattened Universe3 / Universe4 */
 typedef struct eu_renderer eu_renderer;  /* a scene resident in one GPU's HBM + work buffers */
@@ -45,9 +47,13 @@ typedef struct {
     int32_t dim;                 /* 3 or 4, must equal the scene's */
     uint32_t fov_deg;            /* diagonal field of view in degrees (u8 in the reference) */
     uint32_t max_depth;          /* Camera::max_depth(), universe/mod.rs:290,310 */
-    uint32_t reserved;
+    uint32_t kind;               /* EU_CAMERA_*: which Camera::update applies (only eu_camera_update reads it) */
     double location[4], forward[4], up[4], left[4];
 } eu_camera;
+
+#define EU_CAMERA_PITCH_YAW_3 0u   /* PitchYawCamera3, d3/entity/camera.rs:76-245 */
+#define EU_CAMERA_FREE_3 1u        /* FreeCamera3,     d3/entity/camera.rs:283-451 */
+#define EU_CAMERA_FREE_4 2u        /* FreeCamera4,     d4/entity/camera.rs:34-241 (implied by dim == 4) */
 
 /* One frame = Environment::render's arguments (universe/mod.rs:300-311), plus the multi-GPU partition.
  * Partition: with strip_count <= 1 the renderer traces rows [row_begin,row_end) into a buffer of
@@ -129,6 +135,46 @@ int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
 /* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F>. */
 int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, int32_t x, int32_t y, double rgb[3]);
+
+/* ---- camera motion ("next" row f3 of the scope table) ------------------------------------------------
+ * Universe::trace_path_unknown (universe/mod.rs:273-286): push a point `distance` along `direction`
+ * through surfaces and materials (portals rescale the step; get_path surface.rs:164-197).  Runs on the
+ * GPU against the resident scene.  *found = 1: Some((out_location, out_direction)); 0: None (no
+ * material at `location`).  Vectors have 4 slots, the first `dim` are used. */
+int eu_trace_path(eu_renderer *, const double location[4], const double direction[4], double distance,
+                  double out_location[4], double out_direction[4], int32_t *found);
+
+/* SimulationContext as Camera::update sees it (simulation.rs:29-41): pressed keys, mouse delta, and the
+ * frame's delta time.  mouse_sensitivity / speed are the Camera3Data / FreeCamera4 fields the loader
+ * cannot set (0.01 and 10.0, d3/entity/camera.rs:46-47); 0 selects those defaults. */
+#define EU_KEY_W 0x0001u
+#define EU_KEY_S 0x0002u
+#define EU_KEY_A 0x0004u
+#define EU_KEY_D 0x0008u
+#define EU_KEY_LSHIFT 0x0010u
+#define EU_KEY_LCONTROL 0x0020u
+#define EU_KEY_Q 0x0040u
+#define EU_KEY_E 0x0080u
+#define EU_KEY_C 0x0100u
+#define EU_KEY_M 0x0200u
+#define EU_KEY_I 0x0400u
+#define EU_KEY_O 0x0800u
+#define EU_KEY_K 0x1000u
+#define EU_KEY_L 0x2000u
+typedef struct {
+    uint32_t keys;               /* EU_KEY_* bit set = context.pressed_keys() */
+    int32_t delta_mouse_x, delta_mouse_y;   /* context.delta_mouse */
+    uint32_t reserved;
+    uint64_t delta_time_ms;      /* (delta_time * 1000).as_secs() */
+    double mouse_sensitivity, speed;
+} eu_input;
+
+/* Camera::update = Environment::update (universe/mod.rs:359,399-405; d3/entity/camera.rs:191-245,396-451;
+ * d4/entity/camera.rs:182-241): rotation from mouse/keys on the host, translation through eu_trace_path.
+ * The renderer may be NULL when the input cannot move the camera (delta_time_ms == 0 or no movement key);
+ * otherwise a NULL renderer fails with EU_ERR_NO_DEVICE.  EU_ERR_UNIMPLEMENTED: a 4-D camera crossed a
+ * surface that turned its direction -- the reference panics there; the pose is left as it was. */
+int eu_camera_update(eu_renderer *, eu_camera *, const eu_input *);
 
 /* Device self-test of the elementary functions (fn: 0 acos 1 asin 2 sin 3 cos 4 tan 5 atan2(x,y) 6 sqrt
  * 7 x/y 8 fmod(x,y)); host buffers. */

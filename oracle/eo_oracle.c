@@ -1360,6 +1360,228 @@ static rgba_t trace(tctx *t, uint32_t max_depth, const obj *belongs_to, const do
     return mapped_get_color(t, t->scene->background, pt);
 }
 
+/* Universe::trace_path (universe/mod.rs:186-227) with ComposableSurface::get_path (surface.rs:164-197) and
+ * Material::trace_path (material.rs:54-56,144-146) inlined where the reference calls them.  The reference recurses
+ * (every level returns its callee's result unchanged); so does this.  A step cap stands in for the stack overflow an
+ * endless chain of grazing hits would end in: beyond EO_PATH_MAX_STEPS levels the call fails (-1). */
+#define EO_PATH_MAX_STEPS 4096
+static int trace_path(tctx *t, double distance, const obj *belongs_to, const double *loc, const double *dir,
+                      double *out_loc, double *out_dir, int level) {
+    int D = t->D;
+    if (level > EO_PATH_MAX_STEPS) { t->stats.errors++; return -1; }
+    trace_ctx c;
+    if (trace_closest(t, belongs_to, loc, dir, &c)) {                         /* filter: surface().is_some(), mod.rs:194-196 */
+        if (!(distance - c.intersection.distance <= 0.0)) {                   /* surface.rs:165-167 */
+            double new_distance = distance - c.intersection.distance;
+            double new_origin[MAXD], tdir[MAXD];
+            for (int i = 0; i < D; i++) new_origin[i] = c.intersection.location[i] + -c.normal_closer[i] * EO_EPS128_A * 128.0;
+            const obj *dest = c.exiting ? material_at(t, new_origin) : c.intersection_traceable;   /* surface.rs:177-185 */
+            if (dest) {
+                v_copy(D, c.intersection.direction, tdir);
+                material_exit(t, c.origin_traceable->o1, tdir);               /* surface.rs:188-189 */
+                material_enter(t, dest->o1, tdir);
+                return trace_path(t, new_distance, dest, new_origin, tdir, out_loc, out_dir, level + 1);
+            }
+        }
+    }
+    for (int i = 0; i < D; i++) { out_loc[i] = loc[i] + dir[i] * distance; out_dir[i] = dir[i]; }   /* material.rs:54-56 */
+    material_exit(t, belongs_to->o1, out_dir);                                /* mod.rs:224 */
+    return 1;
+}
+
+/* Universe::trace_path_unknown (universe/mod.rs:273-286): 1 = Some((location, direction)), 0 = None (no material at
+ * `location`), -1 = step cap. */
+int eo_trace_path_unknown(const eo_scene *s, const double *loc, const double *dir, double distance, double *out_loc, double *out_dir) {
+    tctx t;
+    memset(&t, 0, sizeof t);
+    t.scene = s; t.D = s->dim; t.arena_cap = 1u << 20; t.arena = malloc(t.arena_cap);
+    int rc = 0;
+    const obj *belongs_to = material_at(&t, loc);
+    if (belongs_to) {
+        double d[MAXD];
+        v_copy(t.D, dir, d);
+        material_enter(&t, belongs_to->o1, d);
+        rc = trace_path(&t, distance, belongs_to, loc, d, out_loc, out_dir, 0);
+    }
+    free(t.arena);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ Camera::update (camera motion, "next" row f3)
+ * d3/entity/camera.rs:94-145,191-245 (PitchYawCamera3), :299-346,396-451 (FreeCamera3); d4/entity/camera.rs:68-136,182-241
+ * (FreeCamera4); util.rs:301-322.  Third-party pieces restated from their published behaviour (parity unpinned): nalgebra
+ * 0.8.2 UnitQuaternion::new / rotate, cross, Matrix4 (column-major storage), approx_eq_ulps with approx_ulps = 8; det 0.1.0
+ * det_copy! as a first-row Laplace expansion. */
+typedef struct { double w, i, j, k; } quat_t;
+static quat_t quat_from_axisangle(const double *aa) {
+    double sqang = v_nsq(3, aa);
+    quat_t q = { 1.0, 0.0, 0.0, 0.0 };
+    if (sqang == 0.0) return q;
+    double ang = sqrt(sqang);
+    double s = eo_sin(ang / 2.0), c = eo_cos(ang / 2.0);
+    double s_ang = s / ang;
+    q.w = c; q.i = aa[0] * s_ang; q.j = aa[1] * s_ang; q.k = aa[2] * s_ang;
+    return q;
+}
+static void quat_rotate(quat_t q, const double *v, double *out) {
+    double qv[3] = { q.i, q.j, q.k }, t[3], u[3];
+    v_cross3(qv, v, t);
+    t[0] = t[0] * 2.0; t[1] = t[1] * 2.0; t[2] = t[2] * 2.0;
+    v_cross3(qv, t, u);
+    for (int a = 0; a < 3; a++) out[a] = (t[a] * q.w + u[a]) + v[a];
+}
+static void rotate_axis_angle(const double *axis, double angle, double *v) {
+    double aa[3], r[3];
+    v_scale(3, axis, angle, aa);
+    quat_rotate(quat_from_axisangle(aa), v, r);
+    v_copy(3, r, v);
+}
+static void normalize_mut(int D, double *v) { double r[MAXD]; v_normalize(D, v, r); v_copy(D, r, v); }
+static int approx_eq_ulps(double a, double b, uint32_t ulps) {
+    if (a == b) return 1;
+    if (eo_isnan(a) || eo_isnan(b) || signbit(a) != signbit(b)) return 0;
+    int64_t ia, ib;
+    memcpy(&ia, &a, 8); memcpy(&ib, &b, 8);
+    int64_t d = ia - ib;
+    if (d < 0) d = -d;
+    return d < (int64_t)ulps;
+}
+static void rotate_pitch_static(double *forward, double *up, double angle, int snap) {   /* d3/entity/camera.rs:116-137 */
+    static const double Z[3] = { 0.0, 0.0, 1.0 };
+    double axis_h[3];
+    v_cross3(forward, up, axis_h); normalize_mut(3, axis_h);
+    if (snap) {
+        double result_angle = angle_between(3, forward, Z);
+        int to_pole = 0;
+        if (result_angle < angle) to_pole = 1;
+        else if (EO_PI_C - result_angle < -angle) to_pole = -1;
+        if (to_pole) {
+            forward[0] = to_pole > 0 ? 0.0 : -0.0; forward[1] = forward[0]; forward[2] = to_pole > 0 ? 1.0 : -1.0;
+            v_cross3(axis_h, forward, up); normalize_mut(3, up);
+            return;
+        }
+    }
+    rotate_axis_angle(axis_h, angle, forward); normalize_mut(3, forward);
+    v_cross3(axis_h, forward, up); normalize_mut(3, up);
+}
+static double det3x3(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
+    return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+static void find_orthonormal_4(const double *a, const double *b, const double *c, double *out) {   /* util.rs:301-308 */
+    double r[4];
+    r[0] = det3x3(a[1], a[2], a[3], b[1], b[2], b[3], c[1], c[2], c[3]);
+    r[1] = -det3x3(a[0], a[2], a[3], b[0], b[2], b[3], c[0], c[2], c[3]);
+    r[2] = det3x3(a[0], a[1], a[3], b[0], b[1], b[3], c[0], c[1], c[3]);
+    r[3] = -det3x3(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]);
+    v_copy(4, r, out);
+}
+static void mat4_mul_vec(double m[4][4], const double *v, double *out) {   /* m[row][col] */
+    double r[4];
+    for (int a = 0; a < 4; a++) r[a] = v_dot(4, m[a], v);
+    v_copy(4, r, out);
+}
+
+/* returns 0 ok, 1 = the reference reaches unimplemented!() (d4/entity/camera.rs:234), -1 = trace_path step cap */
+int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_input *in) {
+    eo_camera cam = *camera;
+    int D = cam.dim;
+    double sens = in->mouse_sensitivity != 0.0 ? in->mouse_sensitivity : 0.01;
+    double speed = in->speed != 0.0 ? in->speed : 10.0;
+    double delta_millis = (double)in->delta_time_ms / 1000.0;
+    double mx = (double)in->delta_mouse_x, my = (double)in->delta_mouse_y;
+    uint32_t keys = in->keys;
+    double direction[MAXD] = { 0.0, 0.0, 0.0, 0.0 };
+    static const double Z[3] = { 0.0, 0.0, 1.0 };
+    if (D == 3 && kind == EO_CAMERA_PITCH_YAW_3) {
+        if (!(mx * mx + my * my <= 0.0)) {                                   /* update_rotation :94-108 */
+            double dir2[2] = { mx * sens, my * sens };
+            rotate_axis_angle(Z, -dir2[0], cam.forward); normalize_mut(3, cam.forward);     /* rotate_yaw_static :110-114 */
+            rotate_axis_angle(Z, -dir2[0], cam.up); normalize_mut(3, cam.up);
+            rotate_pitch_static(cam.forward, cam.up, -dir2[1], 1);
+        }
+    } else if (D == 3) {                                                     /* FreeCamera3::update_rotation :299-324 */
+        double dir2[2] = { mx * sens, my * sens };
+        double roll = 0.0;
+        if (keys & EO_KEY_Q) roll -= 1.0;
+        if (keys & EO_KEY_E) roll += 1.0;
+        roll *= delta_millis * 2.0;
+        if (dir2[0] != 0.0) { rotate_axis_angle(cam.up, -dir2[0], cam.forward); normalize_mut(3, cam.forward); }
+        if (dir2[1] != 0.0) rotate_pitch_static(cam.forward, cam.up, -dir2[1], 0);
+        if (roll != 0.0) { rotate_axis_angle(cam.forward, roll, cam.up); normalize_mut(3, cam.up); }
+    } else {                                                                 /* FreeCamera4::update_rotation d4:68-126 */
+        double angle = 0.0;
+        if (keys & EO_KEY_C) angle += 1.0;
+        if (keys & EO_KEY_M) angle -= 1.0;
+        if (angle != 0.0) {
+            angle *= delta_millis * 2.0;
+            int ax[4] = { !!(keys & EO_KEY_I), !!(keys & EO_KEY_O), !!(keys & EO_KEY_K), !!(keys & EO_KEY_L) };
+            if (ax[0] + ax[1] + ax[2] + ax[3] == 2) {
+                double storage[16];                                          /* column-major: storage[col*4 + row] */
+                for (int idx = 0; idx < 16; idx++) storage[idx] = (idx / 4 == idx % 4) ? 1.0 : 0.0;
+                for (int idx = 0; idx < 16; idx++) {
+                    int row = idx / 4, column = idx % 4;                     /* the reference's names for them */
+                    if (ax[row] && ax[column]) storage[idx] = row == column ? eo_cos(angle) : (row < column ? -eo_sin(angle) : eo_sin(angle));
+                }
+                double rot[4][4], nm[4][4], nt[4][4], ana[4];
+                for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) rot[r][c] = storage[c * 4 + r];
+                find_orthonormal_4(cam.forward, cam.left, cam.up, ana);
+                for (int r = 0; r < 4; r++) { nm[r][0] = cam.forward[r]; nm[r][1] = cam.left[r]; nm[r][2] = cam.up[r]; nm[r][3] = ana[r]; }
+                for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) nt[r][c] = nm[c][r];
+                double *vs[3] = { cam.forward, cam.left, cam.up };
+                for (int q = 0; q < 3; q++) {
+                    double a1[4], a2[4];
+                    mat4_mul_vec(nt, vs[q], a1); mat4_mul_vec(rot, a1, a2); mat4_mul_vec(nm, a2, vs[q]);
+                }
+                find_orthonormal_4(cam.forward, cam.left, cam.up, ana);
+                find_orthonormal_4(cam.up, cam.left, ana, cam.forward); normalize_mut(4, cam.forward);       /* reorthonormalize_4 util.rs:310-322 */
+                find_orthonormal_4(cam.forward, cam.up, ana, cam.left); normalize_mut(4, cam.left);
+                find_orthonormal_4(cam.forward, ana, cam.left, cam.up); normalize_mut(4, cam.up);
+            }
+        }
+    }
+    double distance = speed * delta_millis;
+    if (distance == 0.0) { *camera = cam; return 0; }
+    double left[MAXD], vertical[MAXD], ana[4] = { 0, 0, 0, 0 };
+    if (D == 3) {
+        v_cross3(cam.up, cam.forward, left); normalize_mut(3, left);         /* get_left :60-62 */
+        v_copy(3, kind == EO_CAMERA_PITCH_YAW_3 ? Z : cam.up, vertical);
+    } else {
+        v_copy(4, cam.left, left); v_copy(4, cam.up, vertical);
+        find_orthonormal_4(cam.forward, cam.left, cam.up, ana);
+    }
+    if (keys & EO_KEY_W) v_add(D, direction, cam.forward, direction);
+    if (keys & EO_KEY_S) v_sub(D, direction, cam.forward, direction);
+    if (keys & EO_KEY_A) v_add(D, direction, left, direction);
+    if (keys & EO_KEY_D) v_sub(D, direction, left, direction);
+    if (keys & EO_KEY_LSHIFT) v_add(D, direction, vertical, direction);
+    if (keys & EO_KEY_LCONTROL) v_sub(D, direction, vertical, direction);
+    if (D == 4 && (keys & EO_KEY_Q)) v_add(D, direction, ana, direction);
+    if (D == 4 && (keys & EO_KEY_E)) v_sub(D, direction, ana, direction);
+    if (v_nsq(D, direction) != 0.0) {
+        distance *= v_norm(D, direction);
+        normalize_mut(D, direction);
+        double nl[MAXD], nd[MAXD];
+        int rc = eo_trace_path_unknown(s, cam.location, direction, distance, nl, nd);
+        if (rc < 0) return -1;
+        if (rc == 1) {
+            double rotation_scale = angle_between(D, direction, nd);
+            if (D == 3) {
+                if (!approx_eq_ulps(rotation_scale, 0.0, 8)) {               /* d3 camera.rs:230-239 */
+                    double axis[3], aa[3], r[3];
+                    v_cross3(direction, nd, axis);
+                    v_scale(3, axis, rotation_scale, aa);
+                    quat_t q = quat_from_axisangle(aa);
+                    quat_rotate(q, cam.forward, r); v_copy(3, r, cam.forward);
+                    quat_rotate(q, cam.up, r); v_copy(3, r, cam.up);
+                }
+            } else if (!approx_eq_ulps(rotation_scale, 0.0, 4 * 8)) return 1;   /* unimplemented!() */
+            v_copy(D, nl, cam.location);
+        }
+    }
+    *camera = cam;
+    return 0;
+}
+
 /* camera ray: d3/entity/camera.rs:155-185 (identical in FreeCamera3 :360-390), d4/entity/camera.rs:146-176 */
 static void camera_ray(const eo_camera *cam, int sx, int sy, int sw, int sh, double *point, double *vector) {
     int D = cam->dim;

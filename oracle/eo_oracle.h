@@ -108,6 +108,24 @@ int eo_default_camera(int dim, const double *location_or_null, eo_camera *out);
 int eo_scene_camera(const eo_scene *, eo_camera *out);
 
 /* the hot path: Environment::render (universe/mod.rs:300-357) */
+/* Universe::trace_path_unknown (universe/mod.rs:273-286): camera motion through surfaces and materials.
+ * Returns 1 = Some, 0 = None, -1 = more than 4096 surface crossings. */
+int eo_trace_path_unknown(const eo_scene *, const double *location, const double *direction, double distance,
+                          double *out_location, double *out_direction);
+
+/* Camera::update (d3/entity/camera.rs:191-245,396-451; d4/entity/camera.rs:182-241). */
+enum { EO_CAMERA_PITCH_YAW_3 = 0, EO_CAMERA_FREE_3 = 1, EO_CAMERA_FREE_4 = 2 };
+enum { EO_KEY_W = 1, EO_KEY_S = 2, EO_KEY_A = 4, EO_KEY_D = 8, EO_KEY_LSHIFT = 16, EO_KEY_LCONTROL = 32, EO_KEY_Q = 64, EO_KEY_E = 128,
+       EO_KEY_C = 256, EO_KEY_M = 512, EO_KEY_I = 1024, EO_KEY_O = 2048, EO_KEY_K = 4096, EO_KEY_L = 8192 };
+typedef struct {
+    uint32_t keys;                       /* context.pressed_keys() */
+    int32_t delta_mouse_x, delta_mouse_y;
+    uint64_t delta_time_ms;              /* (delta_time * 1000).as_secs() */
+    double mouse_sensitivity, speed;     /* 0 = the reference's 0.01 / 10.0 */
+} eo_input;
+/* 0 = updated, 1 = the reference reaches unimplemented!() (4-D, direction turned), -1 = path step cap */
+int eo_camera_update(const eo_scene *, int kind, eo_camera *, const eo_input *);
+
 int eo_render(const eo_scene *, const eo_camera *, const eo_frame *, int threads,
               uint8_t *rgb_out /* (row_end-row_begin)*width*3 */,
               double *hit_t /* optional, per pixel: distance of the primary ray's closest hit, -1 if none */,

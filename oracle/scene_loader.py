@@ -28,6 +28,16 @@ class Frame(C.Structure):
                 ("row_end", C.c_uint32), ("time_ms", C.c_uint64), ("debug_crosshair", C.c_int)]
 
 
+class Input(C.Structure):
+    _fields_ = [("keys", C.c_uint32), ("delta_mouse_x", C.c_int32), ("delta_mouse_y", C.c_int32),
+                ("delta_time_ms", C.c_uint64), ("mouse_sensitivity", C.c_double), ("speed", C.c_double)]
+
+
+CAMERA_KINDS = {"PitchYawCamera3": 0, "FreeCamera3": 1, "FreeCamera4": 2}
+KEYS = {name: 1 << i for i, name in enumerate(
+    ["W", "S", "A", "D", "LShift", "LControl", "Q", "E", "C", "M", "I", "O", "K", "L"])}
+
+
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("bg_samples", C.c_uint64), ("nan_pixels", C.c_uint64),
                 ("errors", C.c_uint64)]
@@ -105,6 +115,8 @@ def lib():
     sig("eo_scene_camera", C.c_int, vp, C.POINTER(Camera))
     sig("eo_render", C.c_int, vp, C.POINTER(Camera), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_void_p,
         C.POINTER(Stats))
+    sig("eo_trace_path_unknown", C.c_int, vp, dp, dp, C.c_double, dp, dp)
+    sig("eo_camera_update", C.c_int, vp, C.c_int, C.POINTER(Camera), C.POINTER(Input))
     sig("eo_test_intersect", C.c_int, vp, C.c_int, dp, dp, C.POINTER(Intersection), C.c_int)
     sig("eo_test_is_point_inside", C.c_int, vp, C.c_int, dp)
     sig("eo_test_angle_between", C.c_double, C.c_int, dp, dp)
@@ -381,17 +393,15 @@ class OracleScene:
         add(["surface_color_texture_%d" % d], [("mapped_texture", "MappedTexture%d" % d)], SC,
             lambda m: ck(L.eo_color_texture(s, m)))
 
-        def cam(loc=None):
+        def cam(kind, loc=None):
             c = Camera()
             L.eo_default_camera(d, dvec(loc) if loc is not None else None, C.byref(c))
+            self.camera_kind = CAMERA_KINDS[kind]      # which Camera::update applies (scene.rs:1353-1408)
             return c
-        if d == 3:
-            add(["PitchYawCamera3", "PitchYawCamera3::new", "FreeCamera3", "FreeCamera3::new"], [], "Camera3", lambda: cam())
-            add(["PitchYawCamera3::new_with_location", "FreeCamera3::new_with_location"], [("location", "Point3")],
-                "Camera3", lambda loc: cam(loc))
-        else:
-            add(["FreeCamera4", "FreeCamera4::new"], [], "Camera4", lambda: cam())
-            add(["FreeCamera4::new_with_location"], [("location", "Point4")], "Camera4", lambda loc: cam(loc))
+        for kind in (["PitchYawCamera3", "FreeCamera3"] if d == 3 else ["FreeCamera4"]):
+            add([kind, kind + "::new"], [], "Camera%d" % d, lambda kind=kind: cam(kind))
+            add([kind + "::new_with_location"], [("location", "Point%d" % d)], "Camera%d" % d,
+                lambda loc, kind=kind: cam(kind, loc))
 
         def universe(camera, entities, background):
             if L.eo_universe(s, C.byref(camera), ivec(entities), len(entities), background) != 0:
@@ -407,6 +417,26 @@ class OracleScene:
         c = Camera()
         self.L.eo_scene_camera(self.s, C.byref(c))
         return c
+
+    def trace_path_unknown(self, distance, location, direction):
+        """Universe::trace_path_unknown -> (location, direction) | None; raises on the step cap."""
+        D = self.dim
+        ol, od = dvec([0.0] * 4), dvec([0.0] * 4)
+        rc = self.L.eo_trace_path_unknown(self.s, dvec(list(location) + [0.0] * (4 - D)),
+                                          dvec(list(direction) + [0.0] * (4 - D)), float(distance), ol, od)
+        if rc < 0:
+            raise RuntimeError("trace_path: step cap")
+        return (tuple(ol)[:D], tuple(od)[:D]) if rc == 1 else None
+
+    def camera_update(self, camera, delta_time_ms, keys=(), delta_mouse=(0, 0), mouse_sensitivity=0.0, speed=0.0,
+                      kind=None):
+        """Camera::update on `camera` (mutated).  Returns 0, or 1 where the reference hits unimplemented!()."""
+        inp = Input(sum(KEYS[k] for k in set(keys)), int(delta_mouse[0]), int(delta_mouse[1]), int(delta_time_ms),
+                    mouse_sensitivity, speed)
+        rc = self.L.eo_camera_update(self.s, self.camera_kind if kind is None else kind, C.byref(camera), C.byref(inp))
+        if rc < 0:
+            raise RuntimeError("trace_path: step cap")
+        return rc
 
     def render(self, width, height, max_depth=None, time_ms=0, threads=None, rows=None, camera=None,
                debug_crosshair=False, want_hit_t=False):

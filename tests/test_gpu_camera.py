@@ -1,0 +1,137 @@
+"""GPU parity of camera motion ("next" row f3): eu_trace_path (Universe::trace_path_unknown on the device) and
+eu_camera_update (Camera::update: host rotation + device translation) against the oracle, bit for bit.
+
+Reference: universe/mod.rs:186-227,273-286; surface.rs:164-197; material.rs:54-56,144-146; d3/entity/camera.rs:191-245,
+396-451; d4/entity/camera.rs:182-241."""
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
+
+
+def both(scene):
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, scene)
+    return Parser().parse_file(path), load_scene_file(path)
+
+
+def rand_unit(rng, D):
+    while True:
+        v = [rng.gauss(0.0, 1.0) for _ in range(D)]
+        n = math.sqrt(sum(x * x for x in v))
+        if n > 1e-3:
+            return [x / n for x in v]
+
+
+@pytest.mark.parametrize("scene,n", [("3d_hallways.json", 300), ("3d_room.json", 300), ("3d_fresnel.json", 100),
+                                     ("3d_photo.json", 100), ("4d_room.json", 150), ("4d_frame.json", 100),
+                                     ("4d_cylinders.json", 60)])
+def test_trace_path_matches_oracle(scene, n):
+    env, osc = both(scene)
+    D = env.dim
+    rng = random.Random(11)
+    base = list(env.camera.location)[:D]
+    crossings = 0
+    for i in range(n):
+        spread = rng.choice([0.0, 2.0, 10.0, 30.0])
+        loc = [b + rng.uniform(-spread, spread) for b in base]
+        d = rand_unit(rng, D) if i % 4 else [1.0 if k == (i // 4) % D else 0.0 for k in range(D)]     # some axis-aligned
+        dist = rng.choice([0.0, 0.05, 1.0, 7.5, 40.0, 250.0])
+        g = env.trace_path_unknown(dist, loc, d)
+        o = osc.trace_path_unknown(dist, loc, d)
+        assert (g is None) == (o is None), (i, loc, d, dist)
+        if g is not None:
+            assert g[0] == o[0] and g[1] == o[1], (i, loc, d, dist, g, o)
+            straight = [a + b * dist for a, b in zip(loc, d)]
+            if max(abs(a - b) for a, b in zip(straight, g[0])) > 1e-9:
+                crossings += 1
+    if scene == "3d_hallways.json":
+        assert crossings > 10           # the sample really walks through portals
+    env.close()
+
+
+def test_flythrough_hallways_pose_and_frames():
+    """Hold W (plus some mouse motion and strafing) for 120 frames of 33 ms at speed 10: the walk passes through the
+    stretching portal of 3d_hallways.  The pose after every update and three rendered frames equal the oracle's."""
+    from euclider_amd import SimulationContext
+    env, osc = both("3d_hallways.json")
+    ocam = osc.camera()
+    env.camera.location[1] = -5.0
+    ocam.location[1] = -5.0
+    env.camera.max_depth = 6
+    rng = random.Random(3)
+    for frame in range(120):
+        keys = ["W"]
+        if frame % 17 == 5:
+            keys.append("A")
+        if frame % 23 == 7:
+            keys.append("LShift")
+        dm = (rng.randint(-3, 3), rng.randint(-2, 2)) if frame % 5 == 0 else (0, 0)
+        env.update(0.033, SimulationContext(pressed_keys=keys, delta_mouse=dm))
+        assert osc.camera_update(ocam, 33, keys, dm) == 0
+        for f in ("location", "forward", "up"):
+            assert list(getattr(env.camera, f))[:3] == list(getattr(ocam, f))[:3], (frame, f)
+        if frame in (30, 60, 119):
+            img = env.render((96, 54), time=frame * 0.033)
+            ocam.max_depth = 6
+            orgb, _, ost = osc.render(96, 54, max_depth=6, time_ms=int(frame * 0.033 * 1000.0), camera=ocam)
+            assert np.array_equal(img.data, orgb), frame
+            assert img.stats["rays"] == ost["rays"]
+    assert env.camera.location[0] > 30.0        # 120 * 0.33 = 39.6 walked, part of it at 4x
+    env.close()
+
+
+def test_free_camera3_walks_through_room():
+    from euclider_amd import SimulationContext, _capi
+    env, osc = both("3d_room.json")
+    env.camera.kind = _capi.EU_CAMERA_FREE_3
+    ocam = osc.camera()
+    rng = random.Random(9)
+    for frame in range(80):
+        keys = [k for k in ("W", "S", "A", "D", "LShift", "LControl", "Q", "E") if rng.random() < 0.35]
+        dm = (rng.randint(-20, 20), rng.randint(-20, 20))
+        env.update(0.016, SimulationContext(pressed_keys=keys, delta_mouse=dm))
+        assert osc.camera_update(ocam, 16, keys, dm, kind=_capi.EU_CAMERA_FREE_3) == 0
+        for f in ("location", "forward", "up"):
+            assert list(getattr(env.camera, f))[:3] == list(getattr(ocam, f))[:3], (frame, f)
+    env.close()
+
+
+def test_free_camera4_moves_or_reports_unimplemented():
+    """FreeCamera4 applies no turn: when trace_path hands back a direction that differs by more than 32 ulps of angle the
+    reference hits `unimplemented!()` (d4/entity/camera.rs:227-235).  Same outcome on both sides, update by update."""
+    from euclider_amd import SimulationContext, _capi
+    from euclider_amd.environment import EuError
+    env, osc = both("4d_room.json")
+    ocam = osc.camera()
+    rng = random.Random(21)
+    outcomes = {0: 0, 1: 0}
+    for frame in range(80):
+        keys = [k for k in ("W", "S", "A", "D", "LShift", "LControl", "Q", "E") if rng.random() < 0.3]
+        if rng.random() < 0.3:
+            keys += [rng.choice(["C", "M"])] + rng.sample(["I", "O", "K", "L"], 2)
+        orc = osc.camera_update(ocam, 16, keys, (0, 0))
+        try:
+            env.update(0.016, SimulationContext(pressed_keys=keys))
+            grc = 0
+        except EuError as e:
+            assert e.code == _capi.EU_ERR_UNIMPLEMENTED
+            grc = 1
+        assert grc == orc, (frame, keys)
+        outcomes[grc] += 1
+        if grc == 1:            # the reference would have panicked: start both from the oracle's (unchanged) pose
+            for f in ("location", "forward", "up", "left"):
+                for k in range(4):
+                    getattr(env.camera, f)[k] = getattr(ocam, f)[k]
+        for f in ("location", "forward", "up", "left"):
+            assert list(getattr(env.camera, f)) == list(getattr(ocam, f)), (frame, f)
+    assert outcomes[0] > 0
+    env.close()
