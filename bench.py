@@ -38,6 +38,10 @@ def parse_args():
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-frame", action="store_true", help="keep width x height for every N (strong scaling, e.g. BASELINE config 5: 7680x4320 on 8 GPUs)")
+    ap.add_argument("--animate", action="store_true",
+                    help="N=1 only, not the headline: fly-through (Camera::update through trace_path each frame) with the frame "
+                         "sequence driver, images read back to pinned host memory -- the PCIe-inclusive rate")
+    ap.add_argument("--slots", type=int, default=2, help="--animate: frames in flight")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
     return ap.parse_args()
 
@@ -97,6 +101,46 @@ def load_traffic(workload_key):
         return None
 
 
+def animate(args, env, scene_path):
+    """Fly-through: every step moves the camera (W held, slow yaw: Camera::update -> eu_trace_path on the GPU), submits the
+    frame to the sequence driver and takes the oldest finished image from pinned host memory."""
+    from euclider_amd import FrameSequence, SimulationContext
+    W, H = args.width, args.height
+    ctx = SimulationContext(resolution=1, pressed_keys=["W"], delta_mouse=(1, 0))
+    rays = 0
+    with FrameSequence(env, (W, H), slots=args.slots) as seq:
+        def step(k):
+            env.update(0.008, ctx, speed=2.0)
+            if seq.in_flight == args.slots:
+                img = seq.next(copy=False)
+                return img.stats["rays"]
+            seq.submit((W, H), time=k * 0.008)
+            return 0
+        for k in range(args.warmup):
+            step(k)
+        while seq.in_flight:
+            seq.next(copy=False)
+        t0 = time.perf_counter()
+        taken = 0
+        k = 0
+        while taken < args.steps:
+            if seq.in_flight == args.slots or k >= args.steps:
+                rays += seq.next(copy=False).stats["rays"]
+                taken += 1
+            if k < args.steps:
+                env.update(0.008, ctx, speed=2.0)
+                seq.submit((W, H), time=(args.warmup + k) * 0.008)
+                k += 1
+        elapsed = time.perf_counter() - t0
+    out = {"metric": "Mray/s, fly-through incl. Camera::update and read-back to pinned host memory (not the headline)",
+           "value": rays / elapsed / 1e6, "unit": "Mray/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "fps": args.steps / elapsed, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s %dx%d depth %d fly-through, %d frames in flight" % (args.scene, W, H, args.max_depth, args.slots),
+                      "camera_end": list(env.camera.location)[:env.dim], "readback_bytes_per_frame": W * H * 3}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +172,12 @@ def main():
     scene_path = os.path.join(ROOT, "scenes", args.scene)
     env = Parser().parse_file(scene_path)
     env.camera.max_depth = args.max_depth
+    if args.animate:
+        if world != 1:
+            raise SystemExit("--animate is a one-GPU mode")
+        animate(args, env, scene_path)
+        env.close()
+        return
     W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
     strips = (rank, world) if world > 1 else None
     frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)

@@ -18,6 +18,7 @@ EU_ERR_CAPACITY = -5
 EU_ERR_TEXTURE = -6
 EU_ERR_UNIMPLEMENTED = -7
 EU_ERR_PATH_STEPS = -8
+EU_ERR_BUSY = -9
 
 EU_CAMERA_PITCH_YAW_3, EU_CAMERA_FREE_3, EU_CAMERA_FREE_4 = 0, 1, 2
 KEYS = {name: 1 << i for i, name in enumerate(
@@ -87,6 +88,11 @@ SYMBOLS = {
                             C.POINTER(Stats)]),
     "eu_trace_screen_point": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_int32, C.c_int32,
                                          C.POINTER(C.c_double)]),
+    "eu_sequence_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "eu_sequence_destroy": (None, [C.c_void_p]),
+    "eu_sequence_submit": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame)]),
+    "eu_sequence_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                    C.POINTER(Stats)]),
     "eu_trace_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "eu_camera_update": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Input)]),

@@ -530,6 +530,108 @@ extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const
     return EU_OK;
 }
 
+/* ------------------------------------------------------------------ frame sequences (scope row f4)
+ * The reference's loop renders a frame, uploads it as a texture and only then starts the next one
+ * (simulation.rs:93-150, universe/mod.rs:300-357).  Here a sequence keeps `slots` frames in flight: frame k+1 is traced
+ * on the trace stream while frame k's RGB8 image travels to pinned host memory on the copy stream. */
+struct eu_sequence {
+    eu_renderer *r = nullptr;
+    uint32_t max_pixels = 0;
+    hipStream_t trace_stream = nullptr, copy_stream = nullptr;
+    struct Slot {
+        uint32_t *d_rgba = nullptr; uint8_t *d_rgb = nullptr; EuDevCounters *d_cnt = nullptr;
+        uint8_t *h_rgb = nullptr; EuDevCounters *h_cnt = nullptr;
+        hipEvent_t traced = nullptr, copied = nullptr;
+        uint32_t width = 0, rows = 0;
+    };
+    std::vector<Slot> slots;
+    unsigned long long submitted = 0, taken = 0;
+};
+
+extern "C" void eu_sequence_destroy(eu_sequence *q) {
+    if (!q) return;
+    if (q->r) (void)hipSetDevice(q->r->device);
+    if (q->trace_stream) (void)hipStreamSynchronize(q->trace_stream);
+    if (q->copy_stream) (void)hipStreamSynchronize(q->copy_stream);
+    for (auto &s : q->slots) {
+        if (s.d_rgba) (void)hipFree(s.d_rgba);
+        if (s.d_rgb) (void)hipFree(s.d_rgb);
+        if (s.d_cnt) (void)hipFree(s.d_cnt);
+        if (s.h_rgb) (void)hipHostFree(s.h_rgb);
+        if (s.h_cnt) (void)hipHostFree(s.h_cnt);
+        if (s.traced) (void)hipEventDestroy(s.traced);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+    }
+    if (q->trace_stream) (void)hipStreamDestroy(q->trace_stream);
+    if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
+    delete q;
+}
+
+extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t max_height, uint32_t slots, eu_sequence **out) {
+    if (!r || !out || max_width == 0 || max_height == 0 || slots == 0 || slots > 16) return EU_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(r->device));
+    eu_sequence *q = new eu_sequence();
+    q->r = r;
+    q->max_pixels = max_width * ((max_height + 7u) & ~7u);
+    q->slots.resize(slots);
+    auto fail = [&](hipError_t e, const char *what) { r->err = std::string(what) + ": " + hipGetErrorString(e); eu_sequence_destroy(q); return EU_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&q->trace_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    for (auto &s : q->slots) {
+        if ((e = hipMalloc((void **)&s.d_rgba, (size_t)q->max_pixels * 4)) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipMalloc((void **)&s.d_rgb, (size_t)q->max_pixels * 3 + 16)) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipMalloc((void **)&s.d_cnt, sizeof(EuDevCounters))) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipHostMalloc((void **)&s.h_rgb, (size_t)q->max_pixels * 3 + 16, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipHostMalloc((void **)&s.h_cnt, sizeof(EuDevCounters), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipEventCreateWithFlags(&s.traced, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+    }
+    *out = q;
+    return EU_OK;
+}
+
+extern "C" int eu_sequence_submit(eu_sequence *q, const eu_camera *cam, const eu_frame *f) {
+    if (!q || !cam || !f) return EU_ERR_INVALID_ARGUMENT;
+    eu_renderer *r = q->r;
+    if (q->submitted - q->taken >= q->slots.size()) { r->err = "every slot of the sequence is in flight: take a frame with eu_sequence_next first"; return EU_ERR_BUSY; }
+    const uint32_t rows = eu_frame_local_rows(f);
+    const size_t pixels = (size_t)rows * f->width;
+    if (pixels == 0 || pixels > q->max_pixels) { r->err = "frame does not fit the sequence's buffers"; return EU_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(r->device));
+    eu_sequence::Slot &s = q->slots[q->submitted % q->slots.size()];
+    int rc = render_device_impl(r, cam, f, q->trace_stream, s.d_rgba, nullptr, nullptr);
+    if (rc != EU_OK) return rc;
+    rc = eu_pack_rgb_device(r, s.d_rgba, s.d_rgb, pixels, q->trace_stream);
+    if (rc != EU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_cnt, r->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToDevice, q->trace_stream));   /* the next frame zeroes d_counters */
+    HIP_TRY(hipEventRecord(s.traced, q->trace_stream));
+    HIP_TRY(hipStreamWaitEvent(q->copy_stream, s.traced, 0));
+    HIP_TRY(hipMemcpyAsync(s.h_rgb, s.d_rgb, pixels * 3, hipMemcpyDeviceToHost, q->copy_stream));
+    HIP_TRY(hipMemcpyAsync(s.h_cnt, s.d_cnt, sizeof(EuDevCounters), hipMemcpyDeviceToHost, q->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, q->copy_stream));
+    s.width = f->width; s.rows = rows;
+    q->submitted++;
+    return EU_OK;
+}
+
+extern "C" int eu_sequence_next(eu_sequence *q, const uint8_t **rgb_host, uint32_t *width, uint32_t *rows, eu_stats *stats) {
+    if (!q || !rgb_host) return EU_ERR_INVALID_ARGUMENT;
+    eu_renderer *r = q->r;
+    if (q->taken == q->submitted) { r->err = "no frame in flight"; return EU_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(r->device));
+    eu_sequence::Slot &s = q->slots[q->taken % q->slots.size()];
+    HIP_TRY(hipEventSynchronize(s.copied));
+    q->taken++;
+    *rgb_host = s.h_rgb;
+    if (width) *width = s.width;
+    if (rows) *rows = s.rows;
+    if (stats) { stats->rays = s.h_cnt->rays; stats->bg_samples = s.h_cnt->bg_samples; stats->nan_pixels = s.h_cnt->nan_pixels; stats->errors = s.h_cnt->errors; }
+    if (s.h_cnt->overflow) { r->err = "wavefront queue overflow: raise EU_WF_RAY_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
+    return EU_OK;
+}
+
 /* Universe::trace_path_unknown (universe/mod.rs:273-286) on the resident scene: one lane, synchronous. */
 extern "C" int eu_trace_path(eu_renderer *r, const double location[4], const double direction[4], double distance,
                              double out_location[4], double out_direction[4], int32_t *found) {

@@ -200,6 +200,55 @@ class Environment:
             raise EuError(rc)
 
 
+class FrameSequence:
+    """The frame loop around Environment::render (simulation.rs:93-150) with `slots` frames in flight: `submit` queues a
+    frame (trace + pack + asynchronous read-back into pinned memory) and returns at once, `next` waits for the oldest one.
+    The camera pose is sampled at submit time, so `env.update(...)` may move it between submits."""
+
+    def __init__(self, env, max_dimensions, slots=2, device=0):
+        self.env, self.device = env, device
+        self._h = C.c_void_p()
+        rc = _capi.lib().eu_sequence_create(env.renderer(device), int(max_dimensions[0]), int(max_dimensions[1]), int(slots),
+                                            C.byref(self._h))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        self.in_flight = 0
+
+    def submit(self, dimensions, time=0.0, context=None):
+        context = context or SimulationContext()
+        bw, bh = dimensions[0] // context.resolution, dimensions[1] // context.resolution     # universe/mod.rs:308-309
+        fr = self.env._frame(bw, bh, _duration_to_ms(time), context.debugging)
+        rc = _capi.lib().eu_sequence_submit(self._h, C.byref(self.env.camera), C.byref(fr))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        self.in_flight += 1
+
+    def next(self, copy=True):
+        """RawImage2d of the oldest frame in flight.  With copy=False `.data` aliases the pinned slot (valid until the slot
+        is reused, i.e. for `slots` further submits)."""
+        ptr, w, rows, st = C.c_void_p(), C.c_uint32(), C.c_uint32(), _capi.Stats()
+        rc = _capi.lib().eu_sequence_next(self._h, C.byref(ptr), C.byref(w), C.byref(rows), C.byref(st))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        self.in_flight -= 1
+        buf = (C.c_uint8 * (w.value * rows.value * 3)).from_address(ptr.value)
+        data = np.frombuffer(buf, dtype=np.uint8).reshape(rows.value, w.value, 3)
+        img = RawImage2d(data.copy() if copy else data, w.value, rows.value)
+        img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
+        return img
+
+    def close(self):
+        if self._h:
+            _capi.lib().eu_sequence_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class Parser:
     """scene::Parser (scene.rs:554-1478).  `texture_dirs`: where relative texture paths are resolved
     (the reference resolves them against the process CWD, scene.rs:1053)."""

@@ -35,9 +35,11 @@ extern "C" {
 #define EU_ERR_TEXTURE (-6)
 #define EU_ERR_UNIMPLEMENTED (-7)  /* the reference reaches `unimplemented!()` here (d4/entity/camera.rs:234) */
 #define EU_ERR_PATH_STEPS (-8)     /* eu_trace_path: more than 4096 surface crossings in one call */
+#define EU_ERR_BUSY (-9)           /* eu_sequence_submit: every slot is in flight */
 
 typedef struct eu_scene eu_scene;        /* a parsed + flattened Universe3 / Universe4 */
 typedef struct eu_renderer eu_renderer;  /* a scene resident in one GPU's HBM + work buffers */
+typedef struct eu_sequence eu_sequence;  /* frames in flight: trace of frame k+1 overlaps the read-back of frame k */
 
 /* Camera pose.  The reference's cameras (d3/entity/camera.rs:31-52, d4/entity/camera.rs:34-58)
  * only expose `new` / `new_with_location` to the loader; orientation, fov and max_depth are
@@ -135,6 +137,18 @@ int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
 /* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F>. */
 int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, int32_t x, int32_t y, double rgb[3]);
+
+/* ---- frame sequences ("next" row f4 of the scope table) ---------------------------------------------
+ * The frame loop around Environment::render (simulation.rs:93-150): the reference finishes a frame, uploads it and only
+ * then starts the next.  A sequence keeps up to `slots` frames in flight on its own streams: eu_sequence_submit queues
+ * trace + RGB8 pack + an asynchronous copy into pinned host memory and returns at once; eu_sequence_next waits for the
+ * OLDEST submitted frame and hands out its image (rows of the reference's RawImage2d, valid until `slots` further
+ * submits) and its counters.  Frames may differ in size (the run-time `resolution` divisor, simulation.rs:284-306), time
+ * (time-varying surfaces) and camera.  Do not interleave eu_render* calls on the same renderer while frames are in flight. */
+int eu_sequence_create(eu_renderer *, uint32_t max_width, uint32_t max_height, uint32_t slots, eu_sequence **out);
+void eu_sequence_destroy(eu_sequence *);
+int eu_sequence_submit(eu_sequence *, const eu_camera *, const eu_frame *);
+int eu_sequence_next(eu_sequence *, const uint8_t **rgb_host, uint32_t *width, uint32_t *rows, eu_stats *);
 
 /* ---- camera motion ("next" row f3 of the scope table) ------------------------------------------------
  * Universe::trace_path_unknown (universe/mod.rs:273-286): push a point `distance` along `direction`

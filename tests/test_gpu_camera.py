@@ -135,3 +135,44 @@ def test_free_camera4_moves_or_reports_unimplemented():
             assert list(getattr(env.camera, f)) == list(getattr(ocam, f)), (frame, f)
     assert outcomes[0] > 0
     env.close()
+
+
+def test_frame_sequence_matches_synchronous_renders():
+    """Scope row f4: frames in flight (time-varying Perlin surface of 3d_room, a changing `resolution` divisor, the debug
+    cross-hair, a moving camera) come back in submit order and equal eu_render of the same frame; one of them is also
+    checked against the oracle."""
+    from euclider_amd import FrameSequence, SimulationContext, _capi
+    from euclider_amd.environment import EuError
+    env, osc = both("3d_room.json")
+    env.camera.max_depth = 5
+    plan = []
+    for k in range(7):
+        plan.append(dict(time=0.25 * k, resolution=[1, 2, 1, 4, 1, 1, 2][k], debugging=(k == 3), x=-0.5 * k))
+    expect = []
+    for p in plan:
+        env.camera.location[0] = p["x"]
+        expect.append(env.render((192, 108), time=p["time"], context=SimulationContext(p["resolution"], p["debugging"])))
+    got = []
+    with FrameSequence(env, (192, 108), slots=3) as seq:
+        for k, p in enumerate(plan):
+            if seq.in_flight == 3:
+                got.append(seq.next())
+            env.camera.location[0] = p["x"]
+            seq.submit((192, 108), time=p["time"], context=SimulationContext(p["resolution"], p["debugging"]))
+        with pytest.raises(EuError) as ei:          # 3 in flight: a 4th submit must be refused, not overwrite a slot
+            if seq.in_flight < 3:
+                pytest.skip("plan too short")
+            seq.submit((192, 108))
+        assert ei.value.code == _capi.EU_ERR_BUSY
+        while seq.in_flight:
+            got.append(seq.next())
+    assert len(got) == len(expect)
+    for k, (g, e) in enumerate(zip(got, expect)):
+        assert g.data.shape == e.data.shape, k
+        assert np.array_equal(g.data, e.data), k
+        assert g.stats == e.stats, k
+    ocam = osc.camera()
+    ocam.location[0] = plan[4]["x"]
+    orgb, _, ost = osc.render(192, 108, max_depth=5, time_ms=1000, camera=ocam)
+    assert np.array_equal(got[4].data, orgb) and got[4].stats["rays"] == ost["rays"]
+    env.close()
