@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libeuclider_amd.so")
+LIB_PATH = os.environ.get("EU_LIB_PATH") or os.path.join(HERE, "libeuclider_amd.so")    # EU_LIB_PATH: A/B builds (diagnostics)
 
 EU_OK = 0
 EU_ERR_INVALID_ARGUMENT = -1

@@ -37,6 +37,9 @@
 #define EU_WF_BLOCK 256
 #define EU_WF_WIN 1024        /* rays sorted together in the shade kernel */
 #define EU_WF_KEYS 32
+#ifndef EU_SHADE_WAVES
+#define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
+#endif
 
 /* Diagnostic build only (-DEU_PROFILE_PHASES): s_memtime shares of the shade kernel's sections go to
  * EuDevCounters::phase[]; never to an output.  WF_STAMP(k) closes section k-1 and opens section k. */
@@ -266,17 +269,27 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
         HS.cap = hs_cap;
     }
     LaneCounters cnt = {0, 0, 0, 0};
+#ifdef EU_PROFILE_ISECT       /* diagnostic build: cycles per entity slot (phase[e], e < 14), ray load (14), result store (15) */
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#define IS_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last_; last_ = now_; } while (0)
+#define IS_START() do { last_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IS_STAMP(k) do { } while (0)
+#define IS_START() do { } while (0)
+#endif
     const uint32_t in = gen & 1u;
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     {
         for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+            IS_START();
             const uint32_t i = wf_map_index(pref, B.n_seg, B.seg_cap, v);
             double o[D], d[D];
 #pragma unroll
             for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
             cnt.rays++;
+            IS_STAMP(14);
             /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
             bool have = false;
             double best_t = 0.0;
@@ -284,30 +297,57 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuFlatEntity *E = S.entity(e);
                 if (E->surface < 0) continue;
+#ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
+                if (!(E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d))) {
+                    double t = 0.0; uint32_t code = 0;
+                    const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                    if (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = e; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                IS_STAMP(e < 14 ? e : 13);
+#else
                 if (E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d)) continue;
                 double t = 0.0; uint32_t code = 0;
                 const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
+#endif
             }
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;
             B.hit_ent[i] = best_ent;
             if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i] + root_base] = have ? best_t : -1.0;
+            IS_STAMP(15);
         }
     }
+#ifdef EU_PROFILE_ISECT
+    for (int q = 0; q < 16; q++) {
+        unsigned long long v = ph[q];
+        for (int off = 32; off > 0; off >>= 1) { unsigned long long w2 = __shfl_down(v, off); v = w2 > v ? w2 : v; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters->phase[q], v);
+    }
+#endif
     wf_flush_counters(counters, cnt);
 }
 
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
-template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
+template <int D, bool SCENE_LDS>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
                                                                   EuWfBuffers B, EuDevCounters *counters) {
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
+    /* The hit entity differs from lane to lane, so the surface / colour-program records are read with per-lane
+     * addresses: from a copy of the flat scene in LDS (the L1 is swept by the ray streams, a global read of the
+     * scene usually goes to L2). */
+    const uint64_t *scene_base = scene_g;
+    if constexpr (SCENE_LDS) {
+        for (uint32_t i = threadIdx.x; i < scene_words; i += EU_WF_BLOCK) lds_dyn[i] = scene_g[i];
+        __syncthreads();
+        scene_base = lds_dyn;
+    }
     EuScene S;
-    S.init(scene_g);
+    S.init(scene_base);
     LaneCounters cnt = {0, 0, 0, 0};
 #ifdef EU_PROFILE_PHASES
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, last2_ = 0;
