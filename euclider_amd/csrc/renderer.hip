@@ -74,6 +74,7 @@ struct eu_renderer {
     int device = 0;
     int dim = 3;
     uint32_t hit_cap = 0;
+    uint32_t color_depth = 0;
     uint32_t scene_words = 0;
     uint64_t *d_scene = nullptr;
     std::vector<void *> d_textures;
@@ -136,6 +137,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
     const EuFlatHeader &h = scene->flat.header();
     r->dim = (int)h.dim;
     r->hit_cap = h.hit_cap;
+    r->color_depth = h.color_depth;
     auto failhip = [&](int code) { set_err(err, errlen, r->err); eu_renderer_destroy(r); return code; };
     if (h.hit_cap > 96) { r->err = "scene needs a per-ray hit stack of " + std::to_string(h.hit_cap) + " entries (compiled maximum 96)"; return failhip(EU_ERR_CAPACITY); }
     if (h.list_depth > 8 || h.color_depth > 4 || h.rpn_depth > 8) { r->err = "scene exceeds a compiled stack depth (csg lists 8, colour 4, rpn 8)"; return failhip(EU_ERR_CAPACITY); }
@@ -329,7 +331,10 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel<D>, 0, g_res))) return rc;
-    const bool shade_lds = (size_t)r->scene_words * 8 <= 40 * 1024 && !getenv("EU_SHADE_SCENE_GLOBAL");   /* 3 workgroups per CU stay resident */
+    /* shade kernel's dynamic LDS: the colour-operand stack (color_depth RGBA doubles per lane) and, when three workgroups
+     * per CU still fit (160 KB / 3, minus ~8 KB static), a copy of the flat scene */
+    const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(double) * EU_WF_BLOCK;
+    const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !getenv("EU_SHADE_SCENE_GLOBAL");
     if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
         for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
@@ -354,8 +359,8 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
             if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
             else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
             else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
-            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
-            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
         }
         for (uint32_t g = dc.max_depth; g-- > 0;)
             hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);

@@ -119,21 +119,24 @@ EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
 
 /* ------------------------------------------------------------------ leaves */
 /* sphere (shape.rs:667-693) and cylinder (shape.rs:962-988) share the root selection */
-EU_DEV int quad_roots(double a, double b, double c, double &t_first, double &t_second) {
+struct LeafHits { int n; double t0, t1; };      /* returned by value: reference out-parameters ended up in scratch memory */
+
+EU_DEV LeafHits quad_roots(double a, double b, double c) {
+    LeafHits r = {0, 0.0, 0.0};
     double d = b * b - 4.0 * a * c;
-    if (d < 0.0) return 0;
+    if (d < 0.0) return r;
     double d_sqrt = sqrt(d);
     double t1 = (-b - d_sqrt) / (2.0 * a);
     double t2 = (-b + d_sqrt) / (2.0 * a);
     if (t1 >= 0.0) {
-        t_first = t1;
-        if (t2 >= 0.0) { t_second = t2; return 2; }
-        return 1;
-    } else if (t2 >= 0.0) { t_first = t2; return 1; }
-    return 0;
+        r.t0 = t1; r.n = 1;
+        if (t2 >= 0.0) { r.t1 = t2; r.n = 2; }
+    } else if (t2 >= 0.0) { r.t0 = t2; r.n = 1; }
+    return r;
 }
 
-template <int D> EU_DEV int leaf_hits(uint32_t kind, const double *P, const double *o, const double *d, double &t0, double &t1) {
+template <int D> EU_DEV LeafHits leaf_hits(uint32_t kind, const double *P, const double *o, const double *d) {
+    LeafHits none = {0, 0.0, 0.0};
     switch (kind) {
     case EU_SH_SPHERE: {                                  /* shape.rs:652-731 */
         double rel[D];
@@ -142,13 +145,13 @@ template <int D> EU_DEV int leaf_hits(uint32_t kind, const double *P, const doub
         double a = vnsq<D>(d);
         double b = 2.0 * vdot<D>(d, rel);
         double c = vnsq<D>(rel) - P[D + 1];
-        return quad_roots(a, b, c, t0, t1);
+        return quad_roots(a, b, c);
     }
     case EU_SH_PLANE: case EU_SH_HALFSPACE: {             /* shape.rs:779-809, 843-870 */
         double t = -(vdot<D>(P, o) + P[D]) / vdot<D>(P, d);
-        if (t < 0.0) return 0;
-        t0 = t;
-        return 1;
+        if (t < 0.0) return none;
+        LeafHits r = {1, t, 0.0};
+        return r;
     }
     case EU_SH_CYLINDER: {                                /* shape.rs:935-1027 */
         const double *ax = P + D;
@@ -164,9 +167,9 @@ template <int D> EU_DEV int leaf_hits(uint32_t kind, const double *P, const doub
         double a = vnsq<D>(a_vec);
         double b = (1.0 + 1.0) * vdot<D>(a_vec, c_vec);
         double c = vnsq<D>(c_vec) - P[2 * D + 1];
-        return quad_roots(a, b, c, t0, t1);
+        return quad_roots(a, b, c);
     }
-    default: return 0;                                    /* VoidShape, shape.rs:622-631 */
+    default: return none;                                 /* VoidShape, shape.rs:622-631 */
     }
 }
 
@@ -409,10 +412,9 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             }
             return n;
         }
-        double t0 = 0.0, t1 = 0.0;
-        const int n = leaf_hits<D>(kind, S.params(param), o, d, t0, t1);
-        if (n) { first_t = t0; first_c = root; }
-        return (uint32_t)n;
+        const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
+        if (lh.n) { first_t = lh.t0; first_c = root; }
+        return (uint32_t)lh.n;
     }
     const uint32_t CAP = hs.cap;
     uint32_t sp = 0;          /* entries in use */
@@ -440,11 +442,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             continue;
         }
         if (kind < EU_SH_UNION) {
-            double t0 = 0.0, t1 = 0.0;
-            int n = leaf_hits<D>(kind, S.params(param), o, d, t0, t1);
+            const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
+            int n = lh.n;
             if (sp + 2 > CAP) { cnt.errors++; n = 0; }
-            if (n >= 1) hs.set(sp, t0, i);
-            if (n >= 2) hs.set(sp + 1, t1, i | EU_HIT_SECOND);
+            if (n >= 1) hs.set(sp, lh.t0, i);
+            if (n >= 2) hs.set(sp + 1, lh.t1, i | EU_HIT_SECOND);
             sp += (uint32_t)n;
             lens = (lens << 8) | (uint64_t)n;
             continue;
@@ -539,8 +541,7 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const d
         for (int i = 0; i < D; i++) n[i] = P[D + 2 + i];
         break;
     default: {                                            /* cylinder: axis point of hit 1 serves both hits (shape.rs:999,1017) */
-        double t0 = 0.0, t1 = 0.0;
-        leaf_hits<D>(kind, P, o, d, t0, t1);
+        const double t0 = leaf_hits<D>(kind, P, o, d).t0;
         double l1[D], q[D], v[D];
 #pragma unroll
         for (int i = 0; i < D; i++) l1[i] = o[i] + d[i] * t0;
@@ -1009,8 +1010,9 @@ template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, HitCtx<
 
 /* the surface-colour provider tree, evaluated as a post-order program on a small stack */
 template <int D>
-EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c, double time_s, LaneCounters &cnt) {
-    Rgba st[4];
+EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c, double time_s, LaneCounters &cnt, double *cst, uint32_t stride) {
+    /* stack of at most 4 colours in LDS, lane-interleaved (entry k, channel j of this lane at cst[(4 k + j) * stride]):
+     * a run-time indexed private array would be scratch memory, and every scratch access waits on vmcnt */
     int sp = 0;
     for (uint32_t i = F->color_first; i <= F->color_root; i++) {
         const EuFlatColorOp *C = S.color_op(i);
@@ -1018,7 +1020,8 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c
         switch (C->kind) {
         case EU_COL_UNIFORM: v = Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}; break;       /* surface.rs:424-429 */
         case EU_COL_BLEND: {                                                                  /* surface.rs:295-322 */
-            Rgba dst = st[(sp - 1) & 3], src = st[(sp - 2) & 3];
+            const double *pd = cst + (uint32_t)(((sp - 1) & 3) * 4) * stride, *ps = cst + (uint32_t)(((sp - 2) & 3) * 4) * stride;
+            const Rgba dst = {pd[0], pd[stride], pd[2 * stride], pd[3 * stride]}, src = {ps[0], ps[stride], ps[2 * stride], ps[3 * stride]};
             sp -= 2;
             v = (C->fn == EU_BL_RATIO) ? combine_palette_color(src, dst, C->v[0]) : blend_rgba(C->fn, src, dst);
             break;
@@ -1054,10 +1057,12 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c
         }
         default: v = mapped_get_color(S, C->aux, c.loc, cnt); break;                          /* surface.rs:536-542 */
         }
-        st[sp & 3] = v;
+        if (i == F->color_root) return v;        /* the root's value is the result (post-order: the stack is empty below it) */
+        double *pw = cst + (uint32_t)((sp & 3) * 4) * stride;
+        pw[0] = v.r; pw[stride] = v.g; pw[2 * stride] = v.b; pw[3 * stride] = v.a;
         sp++;
     }
-    return st[0];
+    return Rgba{0.0, 0.0, 0.0, 0.0};     /* not reached: color_first <= color_root */
 }
 
 #endif

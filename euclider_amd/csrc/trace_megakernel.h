@@ -184,7 +184,8 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 double t_o[D], t_d[D];
                 int dest = -1;
                 if (!(ratio >= 1.0)) {                                              /* get_intersection_color */
-                    const Rgba sc = surface_color<D>(S, F, c, fr.time_s, cnt);
+                    double cst_priv[16];
+                    const Rgba sc = surface_color<D>(S, F, c, fr.time_s, cnt, cst_priv, 1u);
                     spx = to_pixel4(sc, cnt);
                     if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
                     else {

@@ -35,7 +35,9 @@
 #include "trace_device.h"
 
 #define EU_WF_BLOCK 256
+#ifndef EU_WF_WIN
 #define EU_WF_WIN 1024        /* rays sorted together in the shade kernel */
+#endif
 #define EU_WF_KEYS 32
 #ifndef EU_SHADE_WAVES
 #define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
@@ -341,10 +343,12 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
      * addresses: from a copy of the flat scene in LDS (the L1 is swept by the ray streams, a global read of the
      * scene usually goes to L2). */
     const uint64_t *scene_base = scene_g;
+    double *color_stack = (double *)lds_dyn;       /* surface_color's operand stack: color_depth RGBA entries per lane (dynamic LDS) */
     if constexpr (SCENE_LDS) {
         for (uint32_t i = threadIdx.x; i < scene_words; i += EU_WF_BLOCK) lds_dyn[i] = scene_g[i];
         __syncthreads();
         scene_base = lds_dyn;
+        color_stack = (double *)(lds_dyn + scene_words);
     }
     EuScene S;
     S.init(scene_base);
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     uint32_t spx = 0;
                     int dest = -1;
                     if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
-                        const Rgba sc = surface_color<D>(S, F, c, time_s, cnt);
+                        const Rgba sc = surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
                         WF_SUB(8);
                         spx = to_pixel4(sc, cnt);
                         WF_SUB(9);
@@ -497,13 +501,16 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             /* children with no depth left (or plain misses) only sample the background
              * (universe/mod.rs:157,183): one code site for all of them */
             WF_STAMP(5);
-            uint32_t n_queue = 0;
+            /* (a lane's children are either all background-only or all queued: the miss case has one child) */
+            const bool bg_only = n_child != 0 && ((c_slot[0] & 2u) != 0 || child_depth == 0);
+            const uint32_t n_queue = bg_only ? 0u : n_child;
 #pragma unroll 1
-            for (uint32_t k = 0; k < 2; k++) {
-                if (k < n_child) {
-                    const bool bg_only = (c_slot[k] & 2u) != 0 || child_depth == 0;
-                    if (bg_only) wf_deliver(B, c_parent[k], c_slot[k] & 1u, wf_background<D>(S, c_d[k], cnt));
-                    else n_queue++;
+            for (uint32_t k = 0; k < 2; k++) {      /* constant indices only: a run-time indexed private array would live in scratch */
+                if (bg_only && k < n_child) {
+                    double dd[D];
+#pragma unroll
+                    for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
+                    wf_deliver(B, k ? c_parent[1] : c_parent[0], (k ? c_slot[1] : c_slot[0]) & 1u, wf_background<D>(S, dd, cnt));
                 }
             }
             WF_STAMP(6);
