@@ -322,7 +322,8 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     const size_t band_pixels = (size_t)band_rows * df_in.width;
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels);
     if (rc != EU_OK) return rc;
-    const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    if (const char *e = getenv("EU_HS_CAP")) hs_cap = (uint32_t)atoi(e);      /* diagnostics only */
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
     const bool hs_lds = r->hit_cap <= 32 && !getenv("EU_HS_PRIVATE");      /* else: private (scratch) hit stack */
