@@ -221,11 +221,13 @@ def main():
     rgba = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     gathered = None
+    allbuf = None
     perm = None
     full = None
     rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(rgba) for _ in range(world)]
+        allbuf = torch.empty((world * max_rows, W), dtype=torch.int32, device=dev)     # the gather lands in place: no concatenation
+        gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
         from euclider_amd.partition import gather_permutation
         perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
         full = torch.empty((H, W), dtype=torch.int32, device=dev)
@@ -244,7 +246,7 @@ def main():
             else:
                 dist.gather(rgba, gathered, dst=0)                  # the single RCCL gather
             if rank == 0:
-                torch.index_select(torch.cat(gathered, 0), 0, perm, out=full)
+                torch.index_select(allbuf, 0, perm, out=full)
                 env.pack_rgb_device(full.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
         else:
             env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
