@@ -516,6 +516,19 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
     if (rc != EU_OK) return rc;
     rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
     if (rc != EU_OK) return rc;
+    if (r->use_wavefront) {
+        /* A frame whose recursion fans out beyond the queues' capacity (more than wf_ray_factor rays per pixel in one
+         * generation) cannot be finished by the wavefront pipeline; the persistent stack-based kernel needs O(depth)
+         * memory per lane whatever the fan-out, so the frame is traced again with it. */
+        EuDevCounters c;
+        HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        if (c.overflow) {
+            r->use_wavefront = false;
+            rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
+            r->use_wavefront = true;
+            if (rc != EU_OK) return rc;
+        }
+    }
     rc = eu_pack_rgb_device(r, r->d_rgba, r->d_rgb, pixels, nullptr);
     if (rc != EU_OK) return rc;
     HIP_TRY(hipMemcpy(rgb_host, r->d_rgb, pixels * 3, hipMemcpyDeviceToHost));

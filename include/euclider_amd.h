@@ -133,7 +133,9 @@ int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
  * (refill, intersect, shade, return); all zero in the shipped build. */
 int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
 
-/* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host. */
+/* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host.  If the frame's
+ * recursion fans out beyond the wavefront queues (reported as EU_ERR_CAPACITY by eu_renderer_stats after the asynchronous
+ * eu_render_device), this call traces it again with the stack-based persistent kernel, which has no such limit. */
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
 /* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F>. */
 int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, int32_t x, int32_t y, double rgb[3]);
