@@ -5,6 +5,7 @@ implementation of the trace path: if the shared library is missing the import fa
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EU_LIB_PATH") or os.path.join(HERE, "libeuclider_amd.so")    # EU_LIB_PATH: A/B builds (diagnostics)
@@ -103,12 +104,32 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same soname as /opt/rocm's).  Whichever copy a process loads
+    first serves both; torch does not find the GPU when it ends up on the system copy, so a process that loads this library
+    BEFORE torch initialises would lose torch's GPU.  Loading torch's copy first (when there is one) makes the order
+    irrelevant.  EU_HIP_RUNTIME=system skips this."""
+    if os.environ.get("EU_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C euclider_amd/csrc` (or __graft_entry__.build()); "
                               "there is no fallback implementation" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)
