@@ -369,10 +369,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     __shared__ uint32_t sorted[EU_WF_WIN];
     __shared__ uint32_t hist[EU_WF_KEYS], offs[EU_WF_KEYS];
     {
-        const uint32_t stride = gridDim.x * EU_WF_WIN;
+        /* a generation too small to give every workgroup a full window is cut into smaller ones: a window's rays are
+         * shaded EU_WF_BLOCK at a time, so its latency (the kernel's critical path) shrinks with it */
+        const uint32_t win = total > gridDim.x * (EU_WF_WIN / 2) ? EU_WF_WIN : (total > gridDim.x * (EU_WF_WIN / 4) ? EU_WF_WIN / 2 : EU_WF_WIN / 4);
+        const uint32_t stride = gridDim.x * win;
         const uint32_t iters = (total + stride - 1) / stride;             /* whole iterations: block-wide append below */
         for (uint32_t it = 0; it < iters; it++) {
-            const uint32_t wbase = it * stride + blockIdx.x * EU_WF_WIN;
+            const uint32_t wbase = it * stride + blockIdx.x * win;
             if (threadIdx.x < EU_WF_KEYS) hist[threadIdx.x] = 0;
             __syncthreads();
             uint32_t myq[EU_WF_WIN / EU_WF_BLOCK], mykey[EU_WF_WIN / EU_WF_BLOCK], myrank[EU_WF_WIN / EU_WF_BLOCK];
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
                 const uint32_t v = wbase + k * EU_WF_BLOCK + threadIdx.x;
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
-                if (v < total) {
+                if (k * EU_WF_BLOCK < win && v < total) {
                     myq[k] = wf_map_index(pref, B.n_seg, B.seg_cap, v);
                     const uint32_t he = B.hit_ent[myq[k]];
                     mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
@@ -393,9 +396,9 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) if (mykey[k] != 0xffffffffu) sorted[offs[mykey[k]] + myrank[k]] = myq[k];
             __syncthreads();
-            const uint32_t n_live = wbase < total ? (total - wbase < EU_WF_WIN ? total - wbase : EU_WF_WIN) : 0u;
+            const uint32_t n_live = wbase < total ? (total - wbase < win ? total - wbase : win) : 0u;
 #pragma unroll 1
-            for (uint32_t sub = 0; sub < EU_WF_WIN / EU_WF_BLOCK; sub++) {
+            for (uint32_t sub = 0; sub * EU_WF_BLOCK < n_live; sub++) {
             const uint32_t sidx = sub * EU_WF_BLOCK + threadIdx.x;
             const bool live = sidx < n_live;
             const uint32_t i = live ? sorted[sidx] : 0u;
