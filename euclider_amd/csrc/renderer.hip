@@ -340,6 +340,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
         for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
     }
+    const uint32_t dbg_skip = getenv("EU_DEBUG_SKIP_ENTITIES") ? ((uint32_t)strtoul(getenv("EU_DEBUG_SKIP_ENTITIES"), nullptr, 0) << 24) : 0u;   /* -DEU_PROFILE_ISECT builds only */
     uint32_t band_no = 0;
     for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows, band_no++) {
         EuDevFrame df = df_in;
@@ -357,7 +358,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
         hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
         for (uint32_t g = 0; g < dc.max_depth; g++) {
-            if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
+            if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words | dbg_skip, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
             else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
             else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
             if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
@@ -472,6 +473,19 @@ extern "C" int eu_renderer_debug_phases(eu_renderer *r, unsigned long long out[1
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; i++) out[i] = c.phase[i];
+    return EU_OK;
+}
+
+extern "C" int eu_renderer_debug_generations(eu_renderer *r, unsigned long long out[17]) {
+    if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int g = 0; g < 17; g++) out[g] = 0;
+    const EuWfBuffers &B = r->wf[0];
+    if (!B.seg_count || !B.n_seg) return EU_OK;
+    std::vector<uint32_t> h((size_t)(EU_MAX_DEPTH + 2) * B.n_seg);
+    HIP_TRY(hipMemcpy(h.data(), B.seg_count, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int g = 0; g < 17 && g < EU_MAX_DEPTH + 2; g++) for (uint32_t i = 0; i < B.n_seg; i++) out[g] += h[(size_t)g * B.n_seg + i];
     return EU_OK;
 }
 

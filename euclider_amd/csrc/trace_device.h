@@ -364,6 +364,58 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
     return len;
 }
 
+/* First element of a Union chain's stream without building the streams (trace_closest only looks at element 0,
+ * universe/mod.rs:114).  Let m be the hit with the strictly smallest t among the leaves' hits, and let its point lie
+ * outside every OTHER half-space of the chain (tested with is_point_inside's own arithmetic, shape.rs:874-880).  Then m is
+ * the first element of every Union node above leaf m (shape.rs:212-264), by induction up the left fold:
+ *   - m comes from the left stream A, B is a leaf: both present -> t_m < t_b strictly, so m is taken and B does not contain
+ *     it -> returned; only A present -> `B.inside(m) ? None : m` -> m;
+ *   - m is the right leaf B, A's stream holds only hits of other leaves (all with larger t): both present -> `a.t < b.t` is
+ *     false, b = m is taken, `A.is_point_inside(m)` is the OR over A's half-spaces -> false -> returned; only B present -> m.
+ * No hit at all -> every stream is empty.  Anything else (a tie, a NaN t, a point inside another half-space) is left to
+ * eval_chain.  Returns 1 (t_out, idx_out), 0 (empty) or -1 (undecided). */
+template <int D>
+EU_DEV int union_chain_first(uint32_t n, const double *P, const double *o, const double *d, double &t_out, uint32_t &idx_out) {
+    double tk[EU_CHAIN_MAX];
+    uint32_t pres = 0;
+    bool has_nan = false;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        tk[k] = 0.0;
+        if (k < n) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
+            tk[k] = t;
+            if (!(t < 0.0)) { pres |= 1u << k; if (t != t) has_nan = true; }
+        }
+    }
+    if (pres == 0) return 0;
+    double best = 0.0; uint32_t idx = 0; bool have = false;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        if (k < n && ((pres >> k) & 1u) && (!have || tk[k] < best)) { best = tk[k]; idx = k; have = true; }
+    }
+    bool ok = !has_nan;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        if (k < n && ((pres >> k) & 1u) && k != idx && !(best < tk[k])) ok = false;       /* a tie */
+    }
+    double loc[D];
+#pragma unroll
+    for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * best;
+#pragma unroll
+    for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
+        if (j < n) {
+            const double *Pj = P + j * EU_HS_STRIDE(D);
+            const double r = vdot<D>(Pj, loc) + Pj[D];
+            if (j != idx && Pj[D + 1] == rust_signum(r)) ok = false;                        /* inside another half-space */
+        }
+    }
+    if (!ok) return -1;
+    t_out = best; idx_out = idx;
+    return 1;
+}
+
 /* Exact culling.  The loader gives every bounded entity (sphere, cuboid / hypercuboid, and Union /
  * Intersection / Complement / SymmetricDifference trees over them) a bounding sphere enlarged by 1e-6.
  * If the half-line o + d*t, t >= 0, stays outside it, no hit point of any leaf of the entity lies in the
@@ -404,6 +456,12 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
             if (Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)) return 0u;
+            if (kind == EU_SH_CHAIN_UNION) {
+                double tf = 0.0; uint32_t idx = 0;
+                const int q = union_chain_first<D>(count, Pc, o, d, tf, idx);
+                if (q == 0) return 0u;
+                if (q > 0) { first_t = tf; first_c = root | (idx << 16); return 1u; }
+            }
             const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, Pc, o, d, tk, list);
             if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
 #pragma unroll

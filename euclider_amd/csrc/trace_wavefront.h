@@ -74,15 +74,27 @@ struct EuWfBuffers {
 };
 
 EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) {
+    /* one atomic per counter and WORKGROUP: same-address atomics drain at ~90 per microsecond, a per-wave flush of a
+     * 768-workgroup launch kept the kernel alive for tens of microseconds after its last ray.  Called by every thread. */
+    __shared__ unsigned long long wg_cnt[4];
+    if (threadIdx.x < 4) wg_cnt[threadIdx.x] = 0ull;
+    __syncthreads();
     unsigned long long v0 = cnt.rays, v1 = cnt.bg, v2 = cnt.nan_px, v3 = cnt.errors;
     for (int off = 32; off > 0; off >>= 1) {
         v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (v0) atomicAdd(&counters->rays, v0);
-        if (v1) atomicAdd(&counters->bg_samples, v1);
-        if (v2) atomicAdd(&counters->nan_pixels, v2);
-        if (v3) atomicAdd(&counters->errors, v3);
+        if (v0) atomicAdd(&wg_cnt[0], v0);
+        if (v1) atomicAdd(&wg_cnt[1], v1);
+        if (v2) atomicAdd(&wg_cnt[2], v2);
+        if (v3) atomicAdd(&wg_cnt[3], v3);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (wg_cnt[0]) atomicAdd(&counters->rays, wg_cnt[0]);
+        if (wg_cnt[1]) atomicAdd(&counters->bg_samples, wg_cnt[1]);
+        if (wg_cnt[2]) atomicAdd(&counters->nan_pixels, wg_cnt[2]);
+        if (wg_cnt[3]) atomicAdd(&counters->errors, wg_cnt[3]);
     }
 }
 
@@ -174,6 +186,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
     chunk = (chunk + 63ull) & ~63ull;
     const unsigned long long chunk_begin = (unsigned long long)blockIdx.x * chunk;
     const unsigned long long iters = (chunk + blockDim.x - 1) / blockDim.x;
+    /* every camera ray starts at the camera (get_ray_point, d3/entity/camera.rs:147-153): material_at(origin) is one value per frame */
+    const int cam_ent = material_at<D>(S, cam.location);
     for (unsigned long long it = 0; it < iters; it++) {
         const unsigned long long local = it * blockDim.x + threadIdx.x;
         const unsigned long long item = local < chunk ? chunk_begin + local : total_items;
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
             }
             vnormalize<D>(dl, d);
             /* trace_unknown (universe/mod.rs:253-271) */
-            const int ent = material_at<D>(S, o);
+            const int ent = cam_ent;
             if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
                 const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
                 rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
@@ -284,12 +298,30 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     {
-        for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        /* software pipeline: the next ray of this lane is located and its loads are issued before the current one is
+         * intersected (the kernel keeps 3 waves per SIMD: too few to hide an HBM round trip behind other waves) */
+        const uint32_t v_step = gridDim.x * blockDim.x;
+        uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t i_next = 0;
+        double o_next[D], d_next[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) { o_next[k] = 0.0; d_next[k] = 0.0; }
+        if (v < total) {
+            i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+#pragma unroll
+            for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+        }
+        for (; v < total; v += v_step) {
             IS_START();
-            const uint32_t i = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+            const uint32_t i = i_next;
             double o[D], d[D];
 #pragma unroll
-            for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
+            for (int k = 0; k < D; k++) { o[k] = o_next[k]; d[k] = d_next[k]; }
+            if (v + v_step < total) {
+                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+#pragma unroll
+                for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+            }
             cnt.rays++;
             IS_STAMP(14);
             /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
@@ -299,6 +331,9 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuFlatEntity *E = S.entity(e);
                 if (E->surface < 0) continue;
+#if defined(EU_PROFILE_ISECT) || defined(EU_DEBUG_SKIP)      /* EU_DEBUG_SKIP_ENTITIES (bit e = leave entity e out): cost per entity from PMC / time deltas */
+                if (((scene_words >> 24) >> e) & 1u) continue;
+#endif
 #ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
                 if (!(E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d))) {
                     double t = 0.0; uint32_t code = 0;
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
                 const uint32_t v = wbase + k * EU_WF_BLOCK + threadIdx.x;
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
-                if (k * EU_WF_BLOCK < win && v < total) {
+                if (v < wbase + win && v < total) {
                     myq[k] = wf_map_index(pref, B.n_seg, B.seg_cap, v);
                     const uint32_t he = B.hit_ent[myq[k]];
                     mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;

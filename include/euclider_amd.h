@@ -132,6 +132,8 @@ int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
  * (refill, intersect, shade, return); all zero in the shipped build. */
 int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
+/* Diagnostics: rays queued per generation by the most recent frame's first band (the last band pipeline of buffer set 0). */
+int eu_renderer_debug_generations(eu_renderer *, unsigned long long out[17]);
 
 /* Synchronous convenience = Environment::render: traces the frame and copies RGB8 (and hit_t) to the host.  If the frame's
  * recursion fans out beyond the wavefront queues (reported as EU_ERR_CAPACITY by eu_renderer_stats after the asynchronous
