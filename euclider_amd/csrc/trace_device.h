@@ -79,7 +79,14 @@ struct EuScene {
         kind = (uint32_t)(x & 0xff); count = (uint32_t)((x >> 8) & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
     }
     EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params + off); }
-    EU_DEV const EuFlatEntity *entity(uint32_t e) const { return (const EuFlatEntity *)(w + off_entities + 2 * e); }
+    /* EuFlatEntity by value, unpacked from two 64-bit words: there are no sub-dword scalar loads, a 16-bit field read through
+     * a pointer becomes a VECTOR load followed by s_waitcnt vmcnt(0) -- a full memory drain per entity of the intersect loop */
+    struct EntityView { uint32_t shape_first, shape_root, material; int32_t surface; uint32_t max_hits, bound; };
+    EU_DEV EntityView entity(uint32_t e) const {
+        const uint64_t a = w[off_entities + 2 * e], b = w[off_entities + 2 * e + 1];
+        return EntityView{(uint32_t)(a & 0xffffu), (uint32_t)((a >> 16) & 0xffffu), (uint32_t)((a >> 32) & 0xffffu), (int32_t)(int16_t)(uint16_t)(a >> 48),
+                          (uint32_t)b, (uint32_t)(b >> 32)};
+    }
     EU_DEV const EuFlatSurface *surface(uint32_t s) const { return (const EuFlatSurface *)(w + off_surfaces + 8 * s); }
     EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
     EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
@@ -619,8 +626,8 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const d
 /* Universe::material_at (universe/mod.rs:229-251): first entity containing the point */
 template <int D> EU_DEV int material_at(const EuScene &S, const double *p) {
     for (uint32_t e = 0; e < S.n_entities; e++) {
-        const EuFlatEntity *E = S.entity(e);
-        if (inside_subtree<D>(S, E->shape_first, E->shape_root, p)) return (int)e;
+        const EuScene::EntityView E = S.entity(e);
+        if (inside_subtree<D>(S, E.shape_first, E.shape_root, p)) return (int)e;
     }
     return -1;
 }

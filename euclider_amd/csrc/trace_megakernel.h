@@ -131,7 +131,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
                 continue;
             }
-            material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
+            material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
             depth = cam.max_depth;
             fsp = 0;
             primary = true;
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 cnt.rays++;
                 /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
                 for (uint32_t e = 0; e < S.n_entities; e++) {
-                    const EuFlatEntity *E = S.entity(e);
-                    if (E->surface < 0) continue;
+                    const EuScene::EntityView E = S.entity(e);
+                    if (E.surface < 0) continue;
                     double t = 0.0; uint32_t code = 0;
-                    const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                    const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                     if (n == 0) continue;
                     if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 c.finish(best_t, o, d);
                 hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
                 c.classify();
-                const EuFlatEntity *HE = S.entity(best_ent);
-                const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
+                const EuScene::EntityView HE = S.entity(best_ent);
+                const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
                 double ratio = reflection_ratio<D>(F, c);
                 ratio = rust_max(rust_min(ratio, 1.0), 0.0);
 
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                         for (int i = 0; i < D; i++) t_o[i] = c.loc[i] + -c.nc[i] * EU_EPS * 128.0;
                         dest = c.exiting ? material_at<D>(S, t_o) : (int)best_ent;
                         if (dest >= 0) {
-                            material_apply<D>(S, S.entity((uint32_t)ent)->material, t_d, true);
-                            material_apply<D>(S, S.entity((uint32_t)dest)->material, t_d, false);
+                            material_apply<D>(S, S.entity((uint32_t)ent).material, t_d, true);
+                            material_apply<D>(S, S.entity((uint32_t)dest).material, t_d, false);
                             need_trans = true;
                         }
                     }

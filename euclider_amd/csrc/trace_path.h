@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
     res.found = 0; res.steps = 0;
     int ent = material_at<D>(S, o);                                         /* universe/mod.rs:280 */
     if (ent >= 0) {
-        material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);  /* enter, :283 */
+        material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);  /* enter, :283 */
         res.found = -1;
         for (uint32_t step = 0; step <= EU_PATH_MAX_STEPS; step++) {
             /* trace_closest over surfaced entities (universe/mod.rs:194-196) */
@@ -45,11 +45,11 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
             double best_t = 0.0;
             uint32_t best_code = 0, best_ent = 0;
             for (uint32_t e = 0; e < S.n_entities; e++) {
-                const EuFlatEntity *E = S.entity(e);
-                if (E->surface < 0) continue;
-                if (E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d)) continue;
+                const EuScene::EntityView E = S.entity(e);
+                if (E.surface < 0) continue;
+                if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
                 double t = 0.0; uint32_t code = 0;
-                const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
             }
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
                 for (int k = 0; k < D; k++) no[k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
                 const int dest = c.exiting ? material_at<D>(S, no) : (int)best_ent;   /* surface.rs:177-185 */
                 if (dest >= 0) {
-                    material_apply<D>(S, S.entity((uint32_t)ent)->material, d, true);     /* exit the origin's material, :188 */
-                    material_apply<D>(S, S.entity((uint32_t)dest)->material, d, false);   /* enter the destination's, :189 */
+                    material_apply<D>(S, S.entity((uint32_t)ent).material, d, true);     /* exit the origin's material, :188 */
+                    material_apply<D>(S, S.entity((uint32_t)dest).material, d, false);   /* enter the destination's, :189 */
                     distance = distance - best_t;
 #pragma unroll
                     for (int k = 0; k < D; k++) o[k] = no[k];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
             if (!moved_on) {                                                 /* Material::trace_path + exit, mod.rs:221-226 */
 #pragma unroll
                 for (int k = 0; k < D; k++) { res.location[k] = o[k] + d[k] * distance; res.direction[k] = d[k]; }
-                material_apply<D>(S, S.entity((uint32_t)ent)->material, res.direction, true);
+                material_apply<D>(S, S.entity((uint32_t)ent).material, res.direction, true);
                 res.found = 1;
                 break;
             }

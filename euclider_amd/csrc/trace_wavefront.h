@@ -247,7 +247,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                 if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
                 break;
             }
-            material_apply<D>(S, S.entity((uint32_t)ent)->material, d, false);
+            material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
             B.node_meta[out_idx - fr.root_base] = WF_ROOT;
             if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
                 wf_deliver(B, out_idx - fr.root_base, 0, wf_background<D>(S, d, cnt));
@@ -329,23 +329,23 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             double best_t = 0.0;
             uint32_t best_code = 0, best_ent = 0xffffffffu;
             for (uint32_t e = 0; e < S.n_entities; e++) {
-                const EuFlatEntity *E = S.entity(e);
-                if (E->surface < 0) continue;
+                const EuScene::EntityView E = S.entity(e);
+                if (E.surface < 0) continue;
 #if defined(EU_PROFILE_ISECT) || defined(EU_DEBUG_SKIP)      /* EU_DEBUG_SKIP_ENTITIES (bit e = leave entity e out): cost per entity from PMC / time deltas */
                 if (((scene_words >> 24) >> e) & 1u) continue;
 #endif
 #ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
-                if (!(E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d))) {
+                if (!(E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d))) {
                     double t = 0.0; uint32_t code = 0;
-                    const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                    const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                     if (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
                 __builtin_amdgcn_wave_barrier();
                 IS_STAMP(e < 14 ? e : 13);
 #else
-                if (E->bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E->bound, D), o, d)) continue;
+                if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
                 double t = 0.0; uint32_t code = 0;
-                const uint32_t n = eval_shape<D>(S, E->shape_first, E->shape_root, o, d, HS, cnt, t, code);
+                const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
 #endif
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
                     c.classify();
                     WF_STAMP(2);
-                    const EuFlatEntity *HE = S.entity(hit_ent);
-                    const EuFlatSurface *F = S.surface((uint32_t)HE->surface);
+                    const EuScene::EntityView HE = S.entity(hit_ent);
+                    const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
                     double ratio = reflection_ratio<D>(F, c);
                     ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
 
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                             dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
                             WF_SUB(11);
                             if (dest >= 0) {
-                                material_apply<D>(S, S.entity(ent)->material, c_d[0], true);
-                                material_apply<D>(S, S.entity((uint32_t)dest)->material, c_d[0], false);
+                                material_apply<D>(S, S.entity(ent).material, c_d[0], true);
+                                material_apply<D>(S, S.entity((uint32_t)dest).material, c_d[0], false);
                                 need_trans = true;
                             }
                         }
