@@ -8,8 +8,8 @@ RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
   N > 1 : the frame grows with N (weak scaling: 1920x1080 pixels per GPU, aspect kept, same
           camera/fov), is cut into 8-row strips dealt round-robin over the ranks (row tiles),
-          each rank traces its strips, and ONE RCCL gather collects them on rank 0, which
-          restores row order and packs RGB8.
+          each rank traces its strips and packs them to RGB8, ONE RCCL gather collects them on
+          rank 0, which restores row order (= the reference's RawImage2d).
 
 Prints one JSON line (rank 0).  `value` = rays of all ranks / max-over-ranks wall time.
 """
@@ -225,29 +225,33 @@ def main():
     perm = None
     full = None
     rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
-    if world > 1 and rank == 0:
-        allbuf = torch.empty((world * max_rows, W), dtype=torch.int32, device=dev)     # the gather lands in place: no concatenation
-        gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
-        from euclider_amd.partition import gather_permutation
-        perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
-        full = torch.empty((H, W), dtype=torch.int32, device=dev)
+    rgb_local = None
+    if world > 1:
+        # every rank packs its own strips to RGB8 before the gather (3 bytes per pixel travel, not 4; the root only reorders rows)
+        rgb_local = torch.empty((max_rows, W * 3), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            allbuf = torch.empty((world * max_rows, W * 3), dtype=torch.uint8, device=dev)   # the gather lands in place: no concatenation
+            gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
+            from euclider_amd.partition import gather_permutation
+            perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
+            full = rgb_out[:H * W * 3].view(H, W * 3)
 
     def step():
         env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
         if world > 1:
+            env.pack_rgb_device(rgba.data_ptr(), rgb_local.data_ptr(), max_rows * W, stream, device=local_rank)
             if smoke_gloo:                                          # one-GPU rehearsal only (see above)
                 torch.cuda.synchronize(dev)
-                host = rgba.cpu()
+                host = rgb_local.cpu()
                 hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, hg, dst=0)
                 if rank == 0:
                     for k in range(world):
                         gathered[k].copy_(hg[k])
             else:
-                dist.gather(rgba, gathered, dst=0)                  # the single RCCL gather
+                dist.gather(rgb_local, gathered, dst=0)             # the single RCCL gather
             if rank == 0:
-                torch.index_select(allbuf, 0, perm, out=full)
-                env.pack_rgb_device(full.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
+                torch.index_select(allbuf, 0, perm, out=full)       # rows back in frame order = the RawImage2d
         else:
             env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
 
