@@ -484,6 +484,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     const uint32_t CAP = hs.cap;
     uint32_t sp = 0;          /* entries in use */
     uint64_t lens = 0;        /* stack of list lengths, 8 bits each (bit 7: stream repeats its last element forever) */
+    /* The reference evaluates streams lazily and trace_closest only asks for element 0; this evaluation is eager.  Where
+     * the eager merge meets something the reference would never finish computing (a stream that neither ends nor yields),
+     * the list is cut there and marked "unknown beyond" (one bit per stacked list).  A parent that runs past such a cut
+     * inherits the mark; only an entity whose FIRST element is unknown counts as an error (the reference would spin). */
+    uint32_t unk = 0;
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, count;
         S.op(i, kind, f, param, count);
@@ -504,6 +509,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             }
             sp += n;
             lens = (lens << 8) | (uint64_t)n;
+            unk <<= 1;
             continue;
         }
         if (kind < EU_SH_UNION) {
@@ -514,6 +520,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if (n >= 2) hs.set(sp + 1, lh.t1, i | EU_HIT_SECOND);
             sp += (uint32_t)n;
             lens = (lens << 8) | (uint64_t)n;
+            unk <<= 1;
             continue;
         }
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
@@ -522,6 +529,9 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         const uint32_t ra = fb - 1, fa = f, rb = i - 1;
         const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
         lens >>= 16;
+        const bool unk_b = (unk & 1u) != 0, unk_a = (unk & 2u) != 0;
+        unk >>= 2;
+        bool out_unk = false;
         const uint32_t nb = lb & 0x7f, na = la & 0x7f;
         const bool rep_a = (la & 0x80) != 0 && na > 0, rep_b = (lb & 0x80) != 0 && nb > 0;
         const uint32_t b0 = sp - nb, a0 = b0 - na, o0 = sp;
@@ -530,8 +540,10 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         const uint32_t guard_max = 4 * (na + nb) + 8;
         for (uint32_t guard = 0;; guard++) {
             const bool sa = ia < na || rep_a, sb = ib < nb || rep_b;
+            if ((!sa && unk_a) || (!sb && unk_b)) { out_unk = true; break; }      /* next() asks both children first (shape.rs:214-215 ...) */
             if (!sa && !sb) break;
-            if (guard >= guard_max || o0 + no >= CAP) { cnt.errors++; break; }   /* runaway (reference would spin) / capacity */
+            if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
+            if (o0 + no >= CAP) { cnt.errors++; break; }                          /* capacity */
             double ta = 0.0, tb = 0.0; uint32_t ca = 0, cb = 0;
             if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
             if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
@@ -571,14 +583,16 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             }
             if (emit) { hs.set(o0 + no, t, c); no++; }
             if (end) break;
-            if (stuck) { if (emit) out_rep = true; else cnt.errors++; break; }   /* no output forever: the reference would spin */
+            if (stuck) { if (emit) out_rep = true; else out_unk = true; break; }   /* no output forever: the reference would spin */
         }
         for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
         sp = a0 + no;
         lens = (lens << 8) | (uint64_t)(no | (out_rep ? 0x80u : 0u));
+        unk = (unk << 1) | (out_unk ? 1u : 0u);
     }
     const uint32_t n = (uint32_t)(lens & 0x7f);
     if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
+    else if (unk & 1u) cnt.errors++;          /* element 0 itself is something the reference never finishes computing */
     return n;
 }
 

@@ -343,6 +343,7 @@ typedef struct {
     uint64_t time_ms;
 } tctx;
 
+#define EO_ARENA_BYTES ((size_t)64 << 20)    /* per thread, touched only as far as used (runaway CSG streams stop at CSG_GUARD) */
 static void *arena_alloc(tctx *t, size_t n) {
     n = (n + 15) & ~(size_t)15;
     if (t->arena_used + n > t->arena_cap) { fprintf(stderr, "eo_oracle: arena exhausted\n"); abort(); }
@@ -390,7 +391,7 @@ static int provider_get(tctx *t, provider *p, int index, hit_t *out) {   /* util
 
 static void negate_normal(int D, hit_t *h) { for (int i = 0; i < D; i++) h->normal[i] = -h->normal[i]; }
 
-#define CSG_GUARD 100000
+#define CSG_GUARD 10000       /* iterations of one next(): the reference would spin forever; counted in stats.errors */
 
 static int iter_next(tctx *t, provider *p, hit_t *out) {
     int D = t->D;
@@ -1394,7 +1395,7 @@ static int trace_path(tctx *t, double distance, const obj *belongs_to, const dou
 int eo_trace_path_unknown(const eo_scene *s, const double *loc, const double *dir, double distance, double *out_loc, double *out_dir) {
     tctx t;
     memset(&t, 0, sizeof t);
-    t.scene = s; t.D = s->dim; t.arena_cap = 1u << 20; t.arena = malloc(t.arena_cap);
+    t.scene = s; t.D = s->dim; t.arena_cap = EO_ARENA_BYTES; t.arena = malloc(t.arena_cap);
     int rc = 0;
     const obj *belongs_to = material_at(&t, loc);
     if (belongs_to) {
@@ -1636,7 +1637,7 @@ static void *worker(void *arg) {
     job_t *j = arg;
     tctx t; memset(&t, 0, sizeof t);
     t.scene = j->scene; t.D = j->scene->dim; t.time_ms = j->frame->time_ms;
-    t.arena_cap = 8u << 20; t.arena = malloc(t.arena_cap);
+    t.arena_cap = EO_ARENA_BYTES; t.arena = malloc(t.arena_cap);
     uint32_t W = j->frame->width, H = j->frame->height;
     uint32_t hw = W / 2, hh = H / 2;
     for (;;) {
@@ -1684,7 +1685,7 @@ int eo_render(const eo_scene *s, const eo_camera *cam, const eo_frame *f, int th
 
 static void tctx_init(tctx *t, const eo_scene *s, int D) {
     memset(t, 0, sizeof *t);
-    t->scene = s; t->D = D; t->arena_cap = 1u << 20; t->arena = malloc(t->arena_cap);
+    t->scene = s; t->D = D; t->arena_cap = EO_ARENA_BYTES; t->arena = malloc(t->arena_cap);
 }
 int eo_test_intersect(const eo_scene *s, int shape, const double *loc, const double *dir, eo_intersection *out, int max_out) {
     obj *sh = get_obj(s, shape, K_SHAPE);

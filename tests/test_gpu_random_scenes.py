@@ -1,0 +1,55 @@
+"""Differential test on random scenes: GPU (through the C ABI) == oracle, bit for bit, on CSG / material / surface
+combinations the shipped scenes do not contain (SymmetricDifference, nested Complements, cylinders with height, hyperplanes
+from vectors, LinearSpace around glass, every blend function, nearest-neighbour textures, camera inside solids, ...)."""
+import os
+
+import numpy as np
+import pytest
+
+from random_scenes import random_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_case(seed, w, h, depth, time_ms=0):
+    from euclider_amd import Parser
+    from euclider_amd.environment import EuError
+    from oracle.scene_loader import OracleScene, default_texture_loader
+    text, dim = random_scene(seed)
+    osc = OracleScene(text, default_texture_loader([ROOT]))
+    orgb, ohit, ost = osc.render(w, h, max_depth=depth, time_ms=time_ms, want_hit_t=True)
+    try:
+        env = Parser(texture_dirs=[ROOT]).parse(text)
+    except Exception as e:          # a capacity the kernels were compiled for (reported, never silent)
+        pytest.skip("scene %d rejected by the product loader: %s" % (seed, e))
+    env.camera.max_depth = depth
+    try:
+        img = env.render((w, h), time=time_ms / 1000.0, want_hit_t=True)
+    except EuError as e:
+        env.close()
+        if e.code == -5:
+            pytest.skip("scene %d exceeds a compiled capacity" % seed)
+        raise
+    env.close()
+    if ost["errors"]:
+        # a CSG stream that never ends (shape.rs:390-392 under an outer operation that keeps asking) or another would-panic
+        # condition: the reference spins or panics there; both sides must say so, the pixels are not defined
+        assert img.stats["errors"] > 0, (seed, img.stats, ost)
+        return
+    diff = np.argwhere(img.data != orgb)
+    assert diff.size == 0, "seed %d: %d differing bytes, first at %s: gpu %s oracle %s" % (
+        seed, len(diff), diff[0], img.data[tuple(diff[0][:2])], orgb[tuple(diff[0][:2])])
+    assert img.stats == ost, (seed, img.stats, ost)
+    both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
+    assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan]), seed
+
+
+@pytest.mark.parametrize("seed", range(0, 120))
+def test_random_scene_parity(seed):
+    run_case(seed, 48, 36, 5, time_ms=250 * (seed % 5))
+
+
+@pytest.mark.parametrize("seed", range(1000, 1012))
+def test_random_scene_parity_deeper_and_larger(seed):
+    run_case(seed, 160, 90, 8)

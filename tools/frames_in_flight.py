@@ -1,0 +1,27 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from euclider_amd import Parser
+dev = torch.device("cuda", 0)
+n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+envs = [Parser().parse_file("scenes/3d_room.json") for _ in range(n_env)]
+for e in envs: e.camera.max_depth = 8
+W, H = 1920, 1080
+streams = [torch.cuda.Stream(dev) for _ in range(n_env)]
+rgba = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(n_env)]
+rgb = [torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) for _ in range(n_env)]
+frames = [e.frame(W, H, time=0.0, rows=(0, H)) for e in envs]
+def step(k):
+    j = k % n_env
+    envs[j].render_device(frames[j], rgba[j].data_ptr(), None, streams[j].cuda_stream, device=0)
+    envs[j].pack_rgb_device(rgba[j].data_ptr(), rgb[j].data_ptr(), H * W, streams[j].cuda_stream, device=0)
+for k in range(6): step(k)
+torch.cuda.synchronize()
+K = 40
+t0 = time.perf_counter()
+for k in range(K): step(k)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+rays = envs[0].stats()["rays"]
+print("envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
+assert torch.equal(rgb[0][:H*W*3], rgb[-1][:H*W*3])
