@@ -743,7 +743,7 @@ struct Flattener {
     }
 
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
-    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth) {
+    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
         op.first = (uint16_t)ops.size();
@@ -774,8 +774,11 @@ struct Flattener {
         } else if (s.kind == Shape::ComposableShape) {
             uint32_t la = emit_shape(*s.sa, base_use, depth);
             uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1);
-            len = la + lb;
-            uint32_t use = base_use + la + lb + len;       /* inputs + merge output */
+            /* a Complement may hand out `a` once more without consuming it (shape.rs:390-392): one element more than it
+             * consumed.  At an entity's root only element 0 is ever looked at, so the extra slot is not reserved there. */
+            const uint32_t extra = s.operation == SetOperation::Complement ? 1u : 0u;
+            len = la + lb + extra;
+            uint32_t use = base_use + la + lb + la + lb + (is_root ? 0u : extra);       /* inputs + merge output */
             if (use > hit_cap) hit_cap = use;
             if (depth + 2 > list_depth) list_depth = depth + 2;
             op.kind = (uint8_t)(EU_SH_UNION + (int)s.operation);
@@ -1028,7 +1031,7 @@ FlatScene flatten(const Universe &u) {
         uint32_t before_cap = f.hit_cap;
         f.hit_cap = 0;
         fe.shape_first = (uint16_t)f.ops.size();
-        f.emit_shape(*e->shape, 0, 0);
+        f.emit_shape(*e->shape, 0, 0, true);
         fe.shape_root = (uint16_t)(f.ops.size() - 1);
         fe.max_hits = f.hit_cap;
         fe.bound = e->surface ? f.entity_bound(*e->shape) : 0xffffffffu;

@@ -543,13 +543,13 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if ((!sa && unk_a) || (!sb && unk_b)) { out_unk = true; break; }      /* next() asks both children first (shape.rs:214-215 ...) */
             if (!sa && !sb) break;
             if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
-            if (o0 + no >= CAP) { cnt.errors++; break; }                          /* capacity */
             double ta = 0.0, tb = 0.0; uint32_t ca = 0, cb = 0;
             if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
             if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
             const bool both = sa && sb;
             const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
             if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
+                if (o0 + no >= CAP) { if (!(i == root && no > 0)) cnt.errors++; break; }  /* capacity (na + nb + 1; at the root only element 0 matters) */
                 hs.set(o0 + no, ta, ca); no++;
                 out_rep = true;
                 break;
@@ -581,9 +581,14 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
                 if (ins) c ^= EU_HIT_FLIP;
                 break;
             }
-            if (emit) { hs.set(o0 + no, t, c); no++; }
+            /* a decision taken on a repeated tail recurs forever with the same outcome (the state did not change): the
+             * element it would emit is the one emitted the step before, so the list is only marked as repeating */
+            if (stuck) { if (emit) out_rep = true; else if (!end) out_unk = true; break; }   /* no output and no end, forever: the reference would spin */
+            if (emit) {
+                if (o0 + no >= CAP) { if (!(i == root && no > 0)) cnt.errors++; break; }   /* capacity (the loader's bound is na + nb) */
+                hs.set(o0 + no, t, c); no++;
+            }
             if (end) break;
-            if (stuck) { if (emit) out_rep = true; else out_unk = true; break; }   /* no output forever: the reference would spin */
         }
         for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
         sp = a0 + no;

@@ -403,7 +403,7 @@ static int iter_next(tctx *t, provider *p, hit_t *out) {
     switch (p->op) {
     case EO_OP_UNION:                                                     /* shape.rs:212-264 */
         for (int guard = 0;; guard++) {
-            if (guard > CSG_GUARD) { t->stats.errors++; return 0; }
+            if (guard > CSG_GUARD) { t->stats.errors++; t->stats.spins++; return 0; }
             int sa = provider_get(t, p->pa, p->index_a, &a);
             int sb = provider_get(t, p->pb, p->index_b, &b);
             if (sa) {
@@ -431,7 +431,7 @@ static int iter_next(tctx *t, provider *p, hit_t *out) {
         }
     case EO_OP_INTERSECTION:                                              /* shape.rs:291-340 */
         for (int guard = 0;; guard++) {
-            if (guard > CSG_GUARD) { t->stats.errors++; return 0; }
+            if (guard > CSG_GUARD) { t->stats.errors++; t->stats.spins++; return 0; }
             int sa = provider_get(t, p->pa, p->index_a, &a);
             int sb = provider_get(t, p->pb, p->index_b, &b);
             if (sa) {
@@ -458,7 +458,7 @@ static int iter_next(tctx *t, provider *p, hit_t *out) {
         }
     case EO_OP_COMPLEMENT:                                                /* shape.rs:365-409 */
         for (int guard = 0;; guard++) {
-            if (guard > CSG_GUARD) { t->stats.errors++; return 0; }
+            if (guard > CSG_GUARD) { t->stats.errors++; t->stats.spins++; return 0; }
             int sa = provider_get(t, p->pa, p->index_a, &a);
             int sb = provider_get(t, p->pb, p->index_b, &b);
             if (sa) {
@@ -1658,7 +1658,7 @@ static void *worker(void *arg) {
     }
     pthread_mutex_lock(&j->mu);
     j->stats.rays += t.stats.rays; j->stats.bg_samples += t.stats.bg_samples;
-    j->stats.nan_pixels += t.stats.nan_pixels; j->stats.errors += t.stats.errors;
+    j->stats.nan_pixels += t.stats.nan_pixels; j->stats.errors += t.stats.errors; j->stats.spins += t.stats.spins;
     pthread_mutex_unlock(&j->mu);
     free(t.arena);
     return NULL;
@@ -1695,6 +1695,19 @@ int eo_test_intersect(const eo_scene *s, int shape, const double *loc, const dou
     int n = 0;
     hit_t h;
     while (n < max_out && provider_get(&t, p, n, &h)) out[n++] = h;
+    free(t.arena);
+    return n;
+}
+/* like eo_test_intersect, for at most max_out elements; *spins = CSG streams that hit the runaway guard on the way */
+int eo_test_intersect_spins(const eo_scene *s, int shape, const double *loc, const double *dir, eo_intersection *out, int max_out, uint64_t *spins) {
+    obj *sh = get_obj(s, shape, K_SHAPE);
+    if (!sh) return -1;
+    tctx t; tctx_init(&t, s, s->dim);
+    provider *p = universe_intersect(&t, loc, dir, sh);
+    int n = 0;
+    hit_t h;
+    while (n < max_out && provider_get(&t, p, n, &h)) out[n++] = h;
+    *spins = t.stats.spins;
     free(t.arena);
     return n;
 }

@@ -50,6 +50,7 @@ typedef struct {
     uint64_t bg_samples;    /* background().get_color calls */
     uint64_t nan_pixels;    /* float->u8 casts that would panic in the reference */
     uint64_t errors;        /* other would-panic conditions (no material, csg runaway, ...) */
+    uint64_t spins;         /* of those: CSG streams the reference would never finish computing (its render would hang) */
 } eo_stats;
 
 typedef struct { double location[4], direction[4], normal[4], distance; } eo_intersection;

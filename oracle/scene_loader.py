@@ -40,7 +40,7 @@ KEYS = {name: 1 << i for i, name in enumerate(
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("bg_samples", C.c_uint64), ("nan_pixels", C.c_uint64),
-                ("errors", C.c_uint64)]
+                ("errors", C.c_uint64), ("spins", C.c_uint64)]
 
 
 class Intersection(C.Structure):
@@ -455,6 +455,7 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("eo_render failed: %d" % rc)
         stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
+        self.last_spins = st.spins      # CSG streams the reference would never finish: the frame is undefined there
         return rgb, hit, stats
 
 

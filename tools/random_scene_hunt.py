@@ -1,0 +1,35 @@
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+from random_scenes import random_scene
+from euclider_amd import Parser
+from euclider_amd.environment import EuError
+from oracle.scene_loader import OracleScene, default_texture_loader
+ROOT = os.getcwd()
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = []; undefined = 0; skipped = 0
+for seed in range(lo, hi):
+    if seed % 200 == 0: print("at seed", seed, "bad so far", len(bad), flush=True)
+    text, dim = random_scene(seed)
+    try:
+        osc = OracleScene(text, default_texture_loader([ROOT]))
+        orgb, ohit, ost = osc.render(40, 30, max_depth=5, time_ms=100 * (seed % 7), want_hit_t=True, threads=8)
+        env = Parser(texture_dirs=[ROOT]).parse(text)
+    except Exception as e:
+        skipped += 1; continue
+    env.camera.max_depth = 5
+    try:
+        img = env.render((40, 30), time=(100 * (seed % 7)) / 1000.0, want_hit_t=True)
+    except EuError as e:
+        env.close(); skipped += 1; continue
+    env.close()
+    if osc.last_spins:
+        undefined += 1
+        continue
+    if not np.array_equal(img.data, orgb) or img.stats != ost:
+        bad.append((seed, int((img.data != orgb).sum()), img.stats, ost))
+        continue
+    nn = ~(np.isnan(img.hit_t) & np.isnan(ohit))
+    if not np.array_equal(img.hit_t[nn], ohit[nn]): bad.append((seed, "hit_t"))
+print("seeds", lo, hi, "bad", len(bad), "undefined", undefined, "skipped", skipped)
+for b in bad[:20]: print(b)
