@@ -54,3 +54,39 @@ def test_random_scene_parity(seed):
 @pytest.mark.parametrize("seed", range(1000, 1012))
 def test_random_scene_parity_deeper_and_larger(seed):
     run_case(seed, 160, 90, 8)
+
+
+@pytest.mark.parametrize("seed", range(300, 340))
+def test_random_scene_trace_path(seed):
+    """Camera motion (Universe::trace_path_unknown) through random scenes: GPU == oracle, bit for bit."""
+    import random
+    from euclider_amd import Parser
+    from euclider_amd.environment import EuError
+    from oracle.scene_loader import OracleScene, default_texture_loader
+    text, dim = random_scene(seed)
+    osc = OracleScene(text, default_texture_loader([ROOT]))
+    try:
+        env = Parser(texture_dirs=[ROOT]).parse(text)
+    except Exception as e:
+        pytest.skip("scene %d rejected by the product loader: %s" % (seed, e))
+    rng = random.Random(seed)
+    base = list(env.camera.location)[:dim]
+    for k in range(12):
+        loc = [b + rng.uniform(-4.0, 14.0 if i == 0 else 4.0) for i, b in enumerate(base)]
+        d = [rng.gauss(0.0, 1.0) for _ in range(dim)]
+        n = sum(x * x for x in d) ** 0.5
+        d = [x / n for x in d]
+        dist = rng.choice([0.5, 3.0, 12.0, 40.0])
+        try:
+            o = osc.trace_path_unknown(dist, loc, d)
+        except RuntimeError:
+            continue                        # step cap in the oracle: the reference would overflow its stack
+        try:
+            g = env.trace_path_unknown(dist, loc, d)
+        except EuError as e:
+            assert e.code in (-5, -8), (seed, k, e.code)
+            continue
+        assert (g is None) == (o is None), (seed, k)
+        if g is not None:
+            assert g == o, (seed, k, loc, d, dist, g, o)
+    env.close()
