@@ -51,6 +51,12 @@ def test_random_scene_parity(seed):
     run_case(seed, 48, 36, 5, time_ms=250 * (seed % 5))
 
 
+@pytest.mark.parametrize("seed", range(20000, 20040))
+def test_random_scene_parity_general_expressions(seed):
+    """Seeds >= 20000 also draw LinearSpace expressions with functions, powers, remainders and several variables."""
+    run_case(seed, 48, 36, 5)
+
+
 @pytest.mark.parametrize("seed", range(1000, 1012))
 def test_random_scene_parity_deeper_and_larger(seed):
     run_case(seed, 160, 90, 8)
