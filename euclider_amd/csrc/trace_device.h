@@ -910,7 +910,10 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
     double pu = 0.5 + eu_atan2(pn[1], pn[0]) / (2.0 * EU_PI_C);
     double pv = 0.5 - eu_asin(pn[2]) / EU_PI_C;
     const uint32_t W = M->w, H = M->h;
-    const uint32_t *tex = (const uint32_t *)M->texels;
+    /* texels live in device (global) memory; the address comes out of the scene blob, so say so: a generic pointer would be
+     * read with flat loads (vmcnt and lgkmcnt both) */
+    typedef const uint32_t __attribute__((address_space(1))) *global_u32_ptr;
+    const global_u32_ptr tex = (global_u32_ptr)(uintptr_t)M->texels;
     if (M->tex_kind == EU_TEX_NEAREST) {                       /* surface.rs:434-451 */
         double x = floor(pu * M->wd), y = floor(pv * M->hd);
         uint32_t xi, yi;
