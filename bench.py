@@ -293,7 +293,7 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         workload = "%s %dx%d depth %d" % (args.scene, W, H, args.max_depth)
         out = {
-            "metric": "Mray/s (primary+secondary) at 1920x1080 depth-8; frac of HBM roofline",
+            "metric": "Mray/s (primary+secondary) at 1920\u00d71080 depth-8; frac of HBM roofline",     # BASELINE.json's metric, verbatim
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.fixed_frame else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
