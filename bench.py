@@ -305,7 +305,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(workload), "kernel": "eu_wf_* frame pipeline (gen, 8x intersect+shade, 8x resolve, final)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms),
-                         "note": "f64-VALU/divergence bound by construction; HBM fraction reported because BASELINE asks for it"},
+                         "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows)
