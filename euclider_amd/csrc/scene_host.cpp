@@ -1040,6 +1040,9 @@ FlatScene flatten(const Universe &u) {
         fe.surface = e->surface ? (int16_t)f.surface_id(e->surface) : (int16_t)-1;
         f.entities.push_back(fe);
     }
+    /* the flat records index with 16 bits (EuFlatEntity, hit codes, EuShapeOp::first): refuse rather than wrap around */
+    if (f.ops.size() > 0xfff0u || f.entities.size() > 0xfff0u || f.materials.size() > 0x7ff0u || f.surfaces.size() > 0x7ff0u)
+        fail(ParserError::CustomError, "the scene exceeds the flat format's 16-bit indices (shape operations, entities, materials or surfaces)");
     uint32_t bg = f.mapped_id(u.background);
     if (u.background->dim != u.dim) fail(ParserError::CustomError, "background dimension mismatch");
 

@@ -12,6 +12,7 @@ class Gen:
     def __init__(self, seed, dim):
         self.r = random.Random(seed)
         self.d = dim
+        self.no_complement = False
         self.seed_variants = seed >= 20000          # later generator features only for new seed ranges (committed seeds keep their scenes)
 
     def num(self, lo, hi, grid=0.25):
@@ -73,7 +74,8 @@ class Gen:
             return self.leaf()
         n = self.r.choice([2, 2, 2, 3])
         parts = [self.shape(depth + 1) for _ in range(n)]
-        return {"ComposableShape%d::of" % self.d: [parts, {"SetOperation": [self.r.choice(OPS)]}]}
+        ops = [o for o in OPS if o != "Complement"] if self.no_complement else OPS     # Complement can make streams that never end
+        return {"ComposableShape%d::of" % self.d: [parts, {"SetOperation": [self.r.choice(ops)]}]}
 
     # ---- materials / surfaces
     def material(self):
@@ -135,10 +137,11 @@ class Gen:
         return {"ComposableSurface%d" % d: {"reflection_ratio": ratio, "reflection_direction": {"reflection_direction_specular_%d" % d: []},
                                             "threshold_direction": thr, "surface_color": self.color()}}
 
-    def scene(self):
+    def scene(self, n_entities=None):
         d = self.d
+        self.no_complement = n_entities is not None      # many-entity scenes: keep every entity's stream finite
         ents = []
-        for _ in range(self.r.randint(1, 5)):
+        for _ in range(n_entities or self.r.randint(1, 5)):
             if self.r.random() < 0.08:
                 ents.append({"Entity%dImpl::new_without_surface" % d: [self.shape(), self.material()]})
             else:
@@ -151,6 +154,6 @@ class Gen:
         return json.dumps({"Universe%d" % d: {"camera": camera, "entities": ents, "background": self.mapped()}})
 
 
-def random_scene(seed, dim=None):
+def random_scene(seed, dim=None, n_entities=None):
     dim = dim or (3 if seed % 3 else 4)
-    return Gen(seed, dim).scene(), dim
+    return Gen(seed, dim).scene(n_entities), dim

@@ -12,17 +12,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_case(seed, w, h, depth, time_ms=0):
+def run_case(seed, w, h, depth, time_ms=0, n_entities=None, min_flat_bytes=0):
     from euclider_amd import Parser
     from euclider_amd.environment import EuError
     from oracle.scene_loader import OracleScene, default_texture_loader
-    text, dim = random_scene(seed)
+    text, dim = random_scene(seed, n_entities=n_entities)
     osc = OracleScene(text, default_texture_loader([ROOT]))
     orgb, ohit, ost = osc.render(w, h, max_depth=depth, time_ms=time_ms, want_hit_t=True)
     try:
         env = Parser(texture_dirs=[ROOT]).parse(text)
     except Exception as e:          # a capacity the kernels were compiled for (reported, never silent)
         pytest.skip("scene %d rejected by the product loader: %s" % (seed, e))
+    assert env.info.flat_bytes >= min_flat_bytes
     env.camera.max_depth = depth
     try:
         img = env.render((w, h), time=time_ms / 1000.0, want_hit_t=True)
@@ -96,3 +97,10 @@ def test_random_scene_trace_path(seed):
         if g is not None:
             assert g == o, (seed, k, loc, d, dist, g, o)
     env.close()
+
+
+@pytest.mark.parametrize("seed,n", [(500, 60), (501, 150), (504, 300), (505, 300)])
+def test_random_scene_parity_many_entities(seed, n):
+    """Scenes far larger than the shipped ones: the flat scene no longer fits the shade kernel's LDS copy (global variant), the
+    sort keys of entities >= 31 share a bucket, hundreds of bounds and materials."""
+    run_case(seed, 64, 48, 4, n_entities=n, min_flat_bytes=45 * 1024 if n >= 150 else 0)

@@ -115,3 +115,15 @@ def test_missing_texture_is_substituted_by_the_procedural_grid():
     # the oracle's loader uses the same generator
     from oracle.scene_loader import procedural_uv_grid as oracle_grid
     assert np.array_equal(g, oracle_grid())
+
+
+def test_scene_beyond_the_flat_format_is_refused():
+    """The flat records hold 16-bit indices: a scene with more shape operations than that is refused, not wrapped around."""
+    leaf = {"Sphere3::new": [{"Point3::new": [5, 0, 0]}, 1]}
+    ents = [entity(leaf) for _ in range(0x10000)]
+    text = json.dumps({"Universe3": {"camera": {"PitchYawCamera3::new": []}, "entities": ents,
+                                     "background": {"MappedTextureImpl3::new": [{"uv_sphere_3": [{"Point3::new": [0, 0, 0]}]},
+                                                                                {"texture_image_linear": ["./resources/none.jpg"]}]}}})
+    with pytest.raises(ParserError) as ei:
+        Parser().parse(text)
+    assert "too many shape nodes" in str(ei.value) or "16-bit" in str(ei.value)
