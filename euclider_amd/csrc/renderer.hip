@@ -71,6 +71,7 @@ __global__ void eu_math_kernel(int fn, const double *x, const double *y, double 
 
 /* ------------------------------------------------------------------ host side */
 struct eu_renderer {
+    std::shared_ptr<const euclider::FlatScene> flat;     /* host copy of the scene: frame sequences clone the renderer per slot */
     int device = 0;
     int dim = 3;
     uint32_t hit_cap = 0;
@@ -125,14 +126,15 @@ extern "C" int eu_device_count(void) {
     return n;
 }
 
-extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer **out, char *err, size_t errlen) {
-    if (!scene || !out) return EU_ERR_INVALID_ARGUMENT;
+static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_scene, int device, eu_renderer **out, char *err, size_t errlen) {
+    struct { const euclider::FlatScene &flat; } scene_ref{*flat_scene}, *scene = &scene_ref;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
         set_err(err, errlen, "no usable HIP device (this library has no CPU fallback)");
         return EU_ERR_NO_DEVICE;
     }
     eu_renderer *r = new eu_renderer();
+    r->flat = flat_scene;
     r->device = device;
     const EuFlatHeader &h = scene->flat.header();
     r->dim = (int)h.dim;
@@ -177,6 +179,11 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
     if (rc != EU_OK) return failhip(rc);
     *out = r;
     return EU_OK;
+}
+
+extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer **out, char *err, size_t errlen) {
+    if (!scene || !out) return EU_ERR_INVALID_ARGUMENT;
+    return renderer_create_impl(std::make_shared<const euclider::FlatScene>(scene->flat), device, out, err, errlen);
 }
 
 extern "C" void eu_renderer_destroy(eu_renderer *r) {
@@ -572,7 +579,12 @@ extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const
 struct eu_sequence {
     eu_renderer *r = nullptr;
     uint32_t max_pixels = 0;
-    hipStream_t trace_stream = nullptr, copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+    /* Every slot traces on its own stream with its own work buffers and counters (a clone of the renderer: the scene and
+     * its textures once more in HBM), so that consecutive frames overlap on the GPU: small frames are bound by the
+     * pipeline's ~0.5 ms of dependent launches, not by throughput. */
+    std::vector<eu_renderer *> slot_renderer;      /* [0] = r */
+    std::vector<hipStream_t> slot_stream;
     struct Slot {
         uint32_t *d_rgba = nullptr; uint8_t *d_rgb = nullptr; EuDevCounters *d_cnt = nullptr;
         uint8_t *h_rgb = nullptr; EuDevCounters *h_cnt = nullptr;
@@ -586,7 +598,7 @@ struct eu_sequence {
 extern "C" void eu_sequence_destroy(eu_sequence *q) {
     if (!q) return;
     if (q->r) (void)hipSetDevice(q->r->device);
-    if (q->trace_stream) (void)hipStreamSynchronize(q->trace_stream);
+    for (hipStream_t st : q->slot_stream) if (st) (void)hipStreamSynchronize(st);
     if (q->copy_stream) (void)hipStreamSynchronize(q->copy_stream);
     for (auto &s : q->slots) {
         if (s.d_rgba) (void)hipFree(s.d_rgba);
@@ -597,8 +609,9 @@ extern "C" void eu_sequence_destroy(eu_sequence *q) {
         if (s.traced) (void)hipEventDestroy(s.traced);
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
-    if (q->trace_stream) (void)hipStreamDestroy(q->trace_stream);
+    for (hipStream_t st : q->slot_stream) if (st) (void)hipStreamDestroy(st);
     if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
+    for (size_t k = 1; k < q->slot_renderer.size(); k++) eu_renderer_destroy(q->slot_renderer[k]);
     delete q;
 }
 
@@ -612,8 +625,18 @@ extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t m
     q->slots.resize(slots);
     auto fail = [&](hipError_t e, const char *what) { r->err = std::string(what) + ": " + hipGetErrorString(e); eu_sequence_destroy(q); return EU_ERR_HIP; };
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&q->trace_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    q->slot_renderer.assign(slots, nullptr);
+    q->slot_stream.assign(slots, nullptr);
+    q->slot_renderer[0] = r;
+    for (uint32_t k = 0; k < slots; k++) {
+        if ((e = hipStreamCreateWithFlags(&q->slot_stream[k], hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        if (k > 0) {
+            char cerr[256] = "";
+            const int crc = renderer_create_impl(r->flat, r->device, &q->slot_renderer[k], cerr, sizeof cerr);
+            if (crc != EU_OK) { r->err = std::string("frame sequence slot: ") + cerr; q->slot_renderer.resize(k); eu_sequence_destroy(q); return crc; }
+        }
+    }
     for (auto &s : q->slots) {
         if ((e = hipMalloc((void **)&s.d_rgba, (size_t)q->max_pixels * 4)) != hipSuccess) return fail(e, "hipMalloc");
         if ((e = hipMalloc((void **)&s.d_rgb, (size_t)q->max_pixels * 3 + 16)) != hipSuccess) return fail(e, "hipMalloc");
@@ -635,13 +658,16 @@ extern "C" int eu_sequence_submit(eu_sequence *q, const eu_camera *cam, const eu
     const size_t pixels = (size_t)rows * f->width;
     if (pixels == 0 || pixels > q->max_pixels) { r->err = "frame does not fit the sequence's buffers"; return EU_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(r->device));
-    eu_sequence::Slot &s = q->slots[q->submitted % q->slots.size()];
-    int rc = render_device_impl(r, cam, f, q->trace_stream, s.d_rgba, nullptr, nullptr);
+    const size_t slot_no = q->submitted % q->slots.size();
+    eu_sequence::Slot &s = q->slots[slot_no];
+    eu_renderer *rs = q->slot_renderer[slot_no];
+    hipStream_t trace_stream = q->slot_stream[slot_no];
+    int rc = render_device_impl(rs, cam, f, trace_stream, s.d_rgba, nullptr, nullptr);
+    if (rc != EU_OK) { if (rs != r) r->err = rs->err; return rc; }
+    rc = eu_pack_rgb_device(rs, s.d_rgba, s.d_rgb, pixels, trace_stream);
     if (rc != EU_OK) return rc;
-    rc = eu_pack_rgb_device(r, s.d_rgba, s.d_rgb, pixels, q->trace_stream);
-    if (rc != EU_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(s.d_cnt, r->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToDevice, q->trace_stream));   /* the next frame zeroes d_counters */
-    HIP_TRY(hipEventRecord(s.traced, q->trace_stream));
+    HIP_TRY(hipMemcpyAsync(s.d_cnt, rs->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToDevice, trace_stream));   /* this slot's next frame zeroes them */
+    HIP_TRY(hipEventRecord(s.traced, trace_stream));
     HIP_TRY(hipStreamWaitEvent(q->copy_stream, s.traced, 0));
     HIP_TRY(hipMemcpyAsync(s.h_rgb, s.d_rgb, pixels * 3, hipMemcpyDeviceToHost, q->copy_stream));
     HIP_TRY(hipMemcpyAsync(s.h_cnt, s.d_cnt, sizeof(EuDevCounters), hipMemcpyDeviceToHost, q->copy_stream));

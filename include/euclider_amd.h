@@ -148,7 +148,9 @@ int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, in
  * trace + RGB8 pack + an asynchronous copy into pinned host memory and returns at once; eu_sequence_next waits for the
  * OLDEST submitted frame and hands out its image (rows of the reference's RawImage2d, valid until `slots` further
  * submits) and its counters.  Frames may differ in size (the run-time `resolution` divisor, simulation.rs:284-306), time
- * (time-varying surfaces) and camera.  Do not interleave eu_render* calls on the same renderer while frames are in flight. */
+ * (time-varying surfaces) and camera.  Every slot traces on its own stream with its own work buffers and counters (the scene
+ * and its textures are resident once per slot), so consecutive frames overlap on the GPU.  Do not interleave eu_render* calls
+ * on the same renderer while frames are in flight. */
 int eu_sequence_create(eu_renderer *, uint32_t max_width, uint32_t max_height, uint32_t slots, eu_sequence **out);
 void eu_sequence_destroy(eu_sequence *);
 int eu_sequence_submit(eu_sequence *, const eu_camera *, const eu_frame *);
