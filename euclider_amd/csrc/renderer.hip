@@ -103,6 +103,11 @@ struct eu_renderer {
     int wf_n_streams = 2;                    /* EU_WF_STREAMS (1 = everything on the caller's stream) */
     double wf_ray_factor = 4.0;
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass (EU_WF_BAND_PIXELS) */
+    /* diagnostic switches, read from the environment once, when the renderer is created */
+    uint32_t dbg_hs_cap = 0;                 /* EU_HS_CAP */
+    bool dbg_hs_private = false;             /* EU_HS_PRIVATE */
+    bool dbg_shade_scene_global = false;     /* EU_SHADE_SCENE_GLOBAL */
+    uint32_t dbg_skip_entities = 0;          /* EU_DEBUG_SKIP_ENTITIES (-DEU_PROFILE_ISECT / -DEU_DEBUG_SKIP builds) */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -166,6 +171,10 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
         r->wf_n_streams = (h.flags & 1u) ? 2 : 1;      /* branching scenes: two band pipelines fill each other's kernel tails (measured: +8 %); others: -5 % */
+        if (const char *k = getenv("EU_HS_CAP")) r->dbg_hs_cap = (uint32_t)atoi(k);
+        r->dbg_hs_private = getenv("EU_HS_PRIVATE") != nullptr;
+        r->dbg_shade_scene_global = getenv("EU_SHADE_SCENE_GLOBAL") != nullptr;
+        if (const char *k = getenv("EU_DEBUG_SKIP_ENTITIES")) r->dbg_skip_entities = (uint32_t)strtoul(k, nullptr, 0) << 24;
         if (const char *k = getenv("EU_WF_STREAMS")) { int v = atoi(k); r->wf_n_streams = v < 1 ? 1 : (v > eu_renderer::WF_MAX_STREAMS ? eu_renderer::WF_MAX_STREAMS : v); }
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
@@ -330,10 +339,10 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels);
     if (rc != EU_OK) return rc;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
-    if (const char *e = getenv("EU_HS_CAP")) hs_cap = (uint32_t)atoi(e);      /* diagnostics only */
+    if (r->dbg_hs_cap) hs_cap = r->dbg_hs_cap;      /* diagnostics only */
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
-    const bool hs_lds = r->hit_cap <= 32 && !getenv("EU_HS_PRIVATE");      /* else: private (scratch) hit stack */
+    const bool hs_lds = r->hit_cap <= 32 && !r->dbg_hs_private;      /* else: private (scratch) hit stack */
     const bool hs_small = !hs_lds && r->hit_cap <= 16;
     if (hs_small) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 16>, 0, g_isect))) return rc; }
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect))) return rc; }
@@ -342,12 +351,12 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     /* shade kernel's dynamic LDS: the colour-operand stack (color_depth RGBA doubles per lane) and, when three workgroups
      * per CU still fit (160 KB / 3, minus ~8 KB static), a copy of the flat scene */
     const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(double) * EU_WF_BLOCK;
-    const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !getenv("EU_SHADE_SCENE_GLOBAL");
+    const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !r->dbg_shade_scene_global;
     if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
         for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
     }
-    const uint32_t dbg_skip = getenv("EU_DEBUG_SKIP_ENTITIES") ? ((uint32_t)strtoul(getenv("EU_DEBUG_SKIP_ENTITIES"), nullptr, 0) << 24) : 0u;   /* -DEU_PROFILE_ISECT builds only */
+    const uint32_t dbg_skip = r->dbg_skip_entities;   /* -DEU_PROFILE_ISECT / -DEU_DEBUG_SKIP builds only */
     uint32_t band_no = 0;
     for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows, band_no++) {
         EuDevFrame df = df_in;
