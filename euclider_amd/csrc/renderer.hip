@@ -108,6 +108,7 @@ struct eu_renderer {
     bool dbg_hs_private = false;             /* EU_HS_PRIVATE */
     bool dbg_shade_scene_global = false;     /* EU_SHADE_SCENE_GLOBAL */
     uint32_t dbg_skip_entities = 0;          /* EU_DEBUG_SKIP_ENTITIES (-DEU_PROFILE_ISECT / -DEU_DEBUG_SKIP builds) */
+    uint32_t dbg_skip_shade = 0;             /* EU_DEBUG_SKIP_SHADE (-DEU_DEBUG_SKIP builds) */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -175,6 +176,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         r->dbg_hs_private = getenv("EU_HS_PRIVATE") != nullptr;
         r->dbg_shade_scene_global = getenv("EU_SHADE_SCENE_GLOBAL") != nullptr;
         if (const char *k = getenv("EU_DEBUG_SKIP_ENTITIES")) r->dbg_skip_entities = (uint32_t)strtoul(k, nullptr, 0) << 24;
+        if (const char *k = getenv("EU_DEBUG_SKIP_SHADE")) r->dbg_skip_shade = (uint32_t)strtoul(k, nullptr, 0) << 16;
         if (const char *k = getenv("EU_WF_STREAMS")) { int v = atoi(k); r->wf_n_streams = v < 1 ? 1 : (v > eu_renderer::WF_MAX_STREAMS ? eu_renderer::WF_MAX_STREAMS : v); }
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
@@ -377,8 +379,8 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
             if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words | dbg_skip, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
             else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
             else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
-            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
-            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth, df.time_s, B, r->d_counters);
+            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters);
+            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters);
         }
         for (uint32_t g = dc.max_depth; g-- > 0;)
             hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);

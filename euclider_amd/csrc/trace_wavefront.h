@@ -369,8 +369,12 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
 
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
 template <int D, bool SCENE_LDS>
-__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, double time_s,
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth /* diagnostic builds: | EU_DEBUG_SKIP_SHADE << 16 */, double time_s,
                                                                   EuWfBuffers B, EuDevCounters *counters) {
+#ifdef EU_DEBUG_SKIP      /* EU_DEBUG_SKIP_SHADE bits (in max_depth's high half): 1 constant background, 2 constant opaque surface colour, 4 ratio 0 */
+    const uint32_t dbg_shade = max_depth >> 16;
+    max_depth &= 0xffffu;
+#endif
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
@@ -469,7 +473,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     WF_STAMP(2);
                     const EuScene::EntityView HE = S.entity(hit_ent);
                     const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
+#ifdef EU_DEBUG_SKIP
+                    double ratio = (dbg_shade & 4u) ? 0.0 : reflection_ratio<D>(F, c);
+#else
                     double ratio = reflection_ratio<D>(F, c);
+#endif
                     ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
 
                     WF_STAMP(3);
@@ -478,7 +486,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     uint32_t spx = 0;
                     int dest = -1;
                     if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
+#ifdef EU_DEBUG_SKIP
+                        const Rgba sc = (dbg_shade & 2u) ? Rgba{0.25, 0.5, 0.75, 1.0} : surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
+#else
                         const Rgba sc = surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
+#endif
                         WF_SUB(8);
                         spx = to_pixel4(sc, cnt);
                         WF_SUB(9);
@@ -548,7 +560,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     double dd[D];
 #pragma unroll
                     for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
+#ifdef EU_DEBUG_SKIP
+                    wf_deliver(B, k ? c_parent[1] : c_parent[0], (k ? c_slot[1] : c_slot[0]) & 1u, (dbg_shade & 1u) ? Rgba{0.1, 0.2, 0.3, 1.0} : wf_background<D>(S, dd, cnt));
+#else
                     wf_deliver(B, k ? c_parent[1] : c_parent[0], (k ? c_slot[1] : c_slot[0]) & 1u, wf_background<D>(S, dd, cnt));
+#endif
                 }
             }
             WF_STAMP(6);
