@@ -7,19 +7,20 @@ from euclider_amd.environment import EuError
 from oracle.scene_loader import OracleScene, default_texture_loader
 ROOT = os.getcwd()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+W, H, DEPTH = int(os.environ.get("HUNT_W", 40)), int(os.environ.get("HUNT_H", 30)), int(os.environ.get("HUNT_DEPTH", 5))
 bad = []; undefined = 0; skipped = 0
 for seed in range(lo, hi):
     if seed % 200 == 0: print("at seed", seed, "bad so far", len(bad), flush=True)
     text, dim = random_scene(seed)
     try:
         osc = OracleScene(text, default_texture_loader([ROOT]))
-        orgb, ohit, ost = osc.render(40, 30, max_depth=5, time_ms=100 * (seed % 7), want_hit_t=True, threads=8)
+        orgb, ohit, ost = osc.render(W, H, max_depth=DEPTH, time_ms=100 * (seed % 7), want_hit_t=True, threads=8)
         env = Parser(texture_dirs=[ROOT]).parse(text)
     except Exception as e:
         skipped += 1; continue
-    env.camera.max_depth = 5
+    env.camera.max_depth = DEPTH
     try:
-        img = env.render((40, 30), time=(100 * (seed % 7)) / 1000.0, want_hit_t=True)
+        img = env.render((W, H), time=(100 * (seed % 7)) / 1000.0, want_hit_t=True)
     except EuError as e:
         env.close(); skipped += 1; continue
     env.close()
