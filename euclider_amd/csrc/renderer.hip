@@ -30,6 +30,7 @@
 #include "trace_device.h"
 #include "trace_megakernel.h"
 #include "trace_wavefront.h"
+#include "trace_stream.h"
 #include "trace_path.h"
 #include "camera_host.hpp"
 
@@ -93,8 +94,21 @@ struct eu_renderer {
     bool have_timing = false;
     int num_cus = 0;
     bool scene_in_lds = true;
+    /* which kernels trace a frame: the persistent stream kernel (trace_stream.h) unless EU_KERNEL says otherwise */
+    enum { PATH_STREAM = 0, PATH_WAVEFRONT = 1, PATH_MEGA = 2 };
+    int path = PATH_STREAM;
+    bool use_wavefront = true;               /* among the two older paths */
+    /* stream kernel: per-workgroup ray chunks + the shared node pool, grown on demand */
+    EuTsPool ts = {};
+    std::vector<void *> ts_allocs;
+    unsigned ts_grid_cap = 0;                /* workgroups the ray chunks / hit rows / counter rows are sized for */
+    uint32_t ts_nch = 0;
+    size_t ts_node_chunks = 0;
+    unsigned ts_grid_last = 0;               /* grid of the most recent launch: that many counter rows are valid */
+    bool ts_last = false;                    /* the most recent frame went through the stream kernel */
+    double ts_node_factor = 6.0;             /* node slots per pixel (EU_TS_NODE_FACTOR); eu_render doubles it after an overflow */
+    unsigned ts_grid_limit = 0;              /* EU_TS_GRID: fewer workgroups than the chip holds (diagnostics) */
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
-    bool use_wavefront = true;
     static constexpr int WF_MAX_STREAMS = 4;
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
@@ -168,15 +182,25 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         }
         r->scene_words = (uint32_t)blob.size();
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
-        if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega";
+        if (const char *k = getenv("EU_KERNEL")) {
+            const std::string ks(k);
+            r->path = ks == "mega" ? eu_renderer::PATH_MEGA : (ks == "wavefront" ? eu_renderer::PATH_WAVEFRONT : eu_renderer::PATH_STREAM);
+            r->use_wavefront = ks != "mega";
+        }
+        if (const char *k = getenv("EU_TS_NODE_FACTOR")) r->ts_node_factor = atof(k);
+        if (const char *k = getenv("EU_TS_GRID")) r->ts_grid_limit = (unsigned)atoi(k);
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
         r->wf_n_streams = (h.flags & 1u) ? 2 : 1;      /* branching scenes: two band pipelines fill each other's kernel tails (measured: +8 %); others: -5 % */
         if (const char *k = getenv("EU_HS_CAP")) r->dbg_hs_cap = (uint32_t)atoi(k);
         r->dbg_hs_private = getenv("EU_HS_PRIVATE") != nullptr;
         r->dbg_shade_scene_global = getenv("EU_SHADE_SCENE_GLOBAL") != nullptr;
+#if defined(EU_DEBUG_SKIP) || defined(EU_PROFILE_ISECT)      /* only the diagnostic builds' kernels mask these bits back out */
         if (const char *k = getenv("EU_DEBUG_SKIP_ENTITIES")) r->dbg_skip_entities = (uint32_t)strtoul(k, nullptr, 0) << 24;
+#endif
+#if defined(EU_DEBUG_SKIP)
         if (const char *k = getenv("EU_DEBUG_SKIP_SHADE")) r->dbg_skip_shade = (uint32_t)strtoul(k, nullptr, 0) << 16;
+#endif
         if (const char *k = getenv("EU_WF_STREAMS")) { int v = atoi(k); r->wf_n_streams = v < 1 ? 1 : (v > eu_renderer::WF_MAX_STREAMS ? eu_renderer::WF_MAX_STREAMS : v); }
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
@@ -202,6 +226,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     (void)hipSetDevice(r->device);
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
+    for (void *p : r->ts_allocs) (void)hipFree(p);
     for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { if (r->wf_stream[k]) (void)hipStreamDestroy(r->wf_stream[k]); if (r->wf_join[k]) (void)hipEventDestroy(r->wf_join[k]); }
     if (r->wf_fork) (void)hipEventDestroy(r->wf_fork);
     if (r->d_scene) (void)hipFree(r->d_scene);
@@ -396,6 +421,90 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     return EU_OK;
 }
 
+/* ------------------------------------------------------------------ stream kernel (trace_stream.h) */
+static int ts_ensure(eu_renderer *r, unsigned grid, uint32_t nch, size_t node_chunks) {
+    if (grid <= r->ts_grid_cap && nch <= r->ts_nch && node_chunks <= r->ts_node_chunks) return EU_OK;
+    if (grid < r->ts_grid_cap) grid = r->ts_grid_cap;
+    if (nch < r->ts_nch) nch = r->ts_nch;
+    if (node_chunks < r->ts_node_chunks) node_chunks = r->ts_node_chunks;
+    for (void *p : r->ts_allocs) (void)hipFree(p);      /* (hipFree waits for the device) */
+    r->ts_allocs.clear();
+    r->ts_grid_cap = 0; r->ts_nch = 0; r->ts_node_chunks = 0;
+    if (node_chunks * (size_t)EU_TS_NCN > 0xfffffff0ull) { r->err = "frame too large for 32-bit node indices; render it in row tiles"; return EU_ERR_CAPACITY; }
+    EuTsPool &P = r->ts;
+    memset(&P, 0, sizeof P);
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(p, bytes));
+        r->ts_allocs.push_back(*p);
+        return EU_OK;
+    };
+    const size_t D = (size_t)r->dim, chunks = (size_t)grid * nch;
+    int rc;
+    if ((rc = alloc((void **)&P.ray_od, chunks * 2 * D * EU_TS_CH * sizeof(double)))) return rc;
+    if ((rc = alloc((void **)&P.ray_parent, chunks * EU_TS_CH * 4))) return rc;
+    if ((rc = alloc((void **)&P.ray_aux, chunks * EU_TS_CH * 4))) return rc;
+    if ((rc = alloc((void **)&P.hit_t, (size_t)grid * EU_TS_CH * 8))) return rc;
+    if ((rc = alloc((void **)&P.hit_code, (size_t)grid * EU_TS_CH * 4))) return rc;
+    if ((rc = alloc((void **)&P.nodes, node_chunks * EU_TS_NCN * sizeof(EuTsNode)))) return rc;
+    if ((rc = alloc((void **)&P.nchunk_prev, node_chunks * 4))) return rc;
+    if ((rc = alloc((void **)&P.wg_counters, (size_t)grid * EU_TS_ROW * sizeof(unsigned long long)))) return rc;
+    P.n_node_chunks = (uint32_t)node_chunks; P.n_wg = grid; P.nch = nch;
+    r->ts_grid_cap = grid; r->ts_nch = nch; r->ts_node_chunks = node_chunks;
+    return EU_OK;
+}
+
+template <int D, int HSCAP, bool LDS>
+static int ts_launch(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
+    auto kern = eu_ts_kernel<D, HSCAP, LDS>;
+    uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    const size_t hs_bytes = HSCAP == 0 ? (size_t)(EU_TS_BLOCK / 64) * hs_cap * 64 * 12 : 0;
+    const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(double) * EU_TS_BLOCK;
+    const size_t shade_bytes = (LDS ? (size_t)r->scene_words * 8 : 0) + color_lds;
+    const size_t lds_bytes = hs_bytes > shade_bytes ? hs_bytes : shade_bytes;      /* the two phases share the space */
+    int blocks_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, EU_TS_BLOCK, lds_bytes));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    unsigned grid = (unsigned)(r->num_cus * blocks_per_cu);
+    if (r->ts_grid_limit && grid > r->ts_grid_limit) grid = r->ts_grid_limit;
+    const unsigned work_tiles = (df.n_tiles + 3u) / 4u;
+    if (grid > work_tiles) grid = work_tiles;
+    if (grid < 1) grid = 1;
+    uint32_t nch = 3u * dc.max_depth + 4u;      /* <= 2 full chunks per generation + 1 open, the one in work and 3 spares */
+    if (nch > EU_TS_NCH) nch = EU_TS_NCH;
+    const size_t pixels = df.single_pixel ? 64 : (size_t)df.local_rows * df.width;
+    const size_t node_chunks = (size_t)((double)pixels * r->ts_node_factor) / EU_TS_NCN + (size_t)grid * (dc.max_depth + 2u) + 1;
+    int rc = ts_ensure(r, grid, nch, node_chunks);
+    if (rc != EU_OK) return rc;
+    EuTsParams prm;
+    memset(&prm, 0, sizeof prm);
+    prm.scene_g = r->d_scene; prm.scene_words = r->scene_words; prm.hs_cap = hs_cap;
+    prm.cam = dc; prm.fr = df; prm.P = r->ts;
+    prm.counters = r->d_counters; prm.rgba = rgba; prm.hit_t_aov = hit_t; prm.point_rgb = point;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(EU_TS_BLOCK), lds_bytes, stream, prm);
+    HIP_TRY(hipGetLastError());
+    r->ts_grid_last = grid;
+    return EU_OK;
+}
+
+template <int D>
+static int ts_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
+    EuDevFrame df = df_in;
+    df.band_row0 = 0; df.band_rows = df.local_rows; df.root_base = 0;
+    const bool hs_lds = r->hit_cap <= 32;      /* else: private (scratch) hit stack */
+    const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(double) * EU_TS_BLOCK;
+    const bool scene_lds = (size_t)r->scene_words * 8 + color_lds <= 48 * 1024 && !r->dbg_shade_scene_global;
+    if (hs_lds) return scene_lds ? ts_launch<D, 0, true>(r, stream, dc, df, rgba, hit_t, point) : ts_launch<D, 0, false>(r, stream, dc, df, rgba, hit_t, point);
+    return scene_lds ? ts_launch<D, 96, true>(r, stream, dc, df, rgba, hit_t, point) : ts_launch<D, 96, false>(r, stream, dc, df, rgba, hit_t, point);
+}
+
+/* rays, background samples, would-panic counters of a stream-kernel frame: one row per workgroup */
+static void ts_sum_rows(const unsigned long long *rows, unsigned n, eu_stats *out, unsigned long long *overflow) {
+    unsigned long long v[5] = {0, 0, 0, 0, 0};
+    for (unsigned w = 0; w < n; w++) for (int k = 0; k < 5; k++) v[k] += rows[(size_t)w * EU_TS_ROW + k];
+    if (out) { out->rays = v[0]; out->bg_samples = v[1]; out->nan_pixels = v[2]; out->errors = v[3]; }
+    *overflow = v[4];
+}
+
 static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_frame *f, hipStream_t stream, uint32_t *rgba, double *hit_t, double *point,
                               bool single = false, uint32_t single_x = 0) {
     if (!r || !cam || !f || !rgba) return EU_ERR_INVALID_ARGUMENT;
@@ -425,7 +534,11 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     const int slot = (int)(r->launches % eu_renderer::EV_RING);
     HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
     hipError_t e = hipSuccess;
-    if (r->use_wavefront) {
+    r->ts_last = r->path == eu_renderer::PATH_STREAM;
+    if (r->path == eu_renderer::PATH_STREAM) {
+        int rc = (r->dim == 3) ? ts_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : ts_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
+        if (rc != EU_OK) return rc;
+    } else if (r->use_wavefront) {
         int rc = (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
         if (rc != EU_OK) return rc;
     } else {
@@ -477,6 +590,14 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
     if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->last_stream));
+    if (r->ts_last) {
+        std::vector<unsigned long long> rows((size_t)r->ts_grid_last * EU_TS_ROW);
+        HIP_TRY(hipMemcpy(rows.data(), r->ts.wg_counters, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long overflow = 0;
+        ts_sum_rows(rows.data(), r->ts_grid_last, out, &overflow);
+        if (overflow) { r->err = "tree-node pool exhausted (" + std::to_string(overflow) + " workgroups stopped): raise EU_TS_NODE_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
+        return EU_OK;
+    }
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c.rays; out->bg_samples = c.bg_samples; out->nan_pixels = c.nan_pixels; out->errors = c.errors;
@@ -488,6 +609,18 @@ extern "C" int eu_renderer_debug_phases(eu_renderer *r, unsigned long long out[1
     if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->last_stream));
+    if (r->ts_last) {      /* -DEU_TS_PROFILE builds: clock shares summed over the workgroups; [11] = workgroups, [12] = the longest workgroup's total */
+        std::vector<unsigned long long> rows((size_t)r->ts_grid_last * EU_TS_ROW);
+        HIP_TRY(hipMemcpy(rows.data(), r->ts.wg_counters, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; i++) out[i] = 0;
+        for (unsigned w = 0; w < r->ts_grid_last; w++) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 11; k++) { out[k] += rows[(size_t)w * EU_TS_ROW + 5 + k]; if (k < 7) tot += rows[(size_t)w * EU_TS_ROW + 5 + k]; }
+            if (tot > out[12]) out[12] = tot;
+        }
+        out[11] = r->ts_grid_last;
+        return EU_OK;
+    }
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; i++) out[i] = c.phase[i];
@@ -548,7 +681,18 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
     if (rc != EU_OK) return rc;
     rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
     if (rc != EU_OK) return rc;
-    if (r->use_wavefront) {
+    if (r->ts_last) {
+        /* The stream kernel's ray queues cannot overflow; its tree-node pool can (more than ts_node_factor nodes per pixel).
+         * The pool is enlarged and the frame traced again. */
+        for (int attempt = 0; attempt < 6; attempt++) {
+            eu_stats tmp;
+            const int src = eu_renderer_stats(r, &tmp);
+            if (src != EU_ERR_CAPACITY) break;
+            r->ts_node_factor = r->ts_node_factor * 2.0 > 2.0 ? r->ts_node_factor * 2.0 : 2.0;
+            rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
+            if (rc != EU_OK) return rc;
+        }
+    } else if (r->use_wavefront) {
         /* A frame whose recursion fans out beyond the queues' capacity (more than wf_ray_factor rays per pixel in one
          * generation) cannot be finished by the wavefront pipeline; the persistent stack-based kernel needs O(depth)
          * memory per lane whatever the fan-out, so the frame is traced again with it. */
@@ -597,14 +741,20 @@ struct eu_sequence {
     std::vector<eu_renderer *> slot_renderer;      /* [0] = r */
     std::vector<hipStream_t> slot_stream;
     struct Slot {
-        uint32_t *d_rgba = nullptr; uint8_t *d_rgb = nullptr; EuDevCounters *d_cnt = nullptr;
-        uint8_t *h_rgb = nullptr; EuDevCounters *h_cnt = nullptr;
+        uint32_t *d_rgba = nullptr; uint8_t *d_rgb = nullptr; unsigned char *d_cnt = nullptr;      /* counters: EuDevCounters, or the stream kernel's per-workgroup rows */
+        uint8_t *h_rgb = nullptr; unsigned char *h_cnt = nullptr; unsigned cnt_rows = 0;        /* h_rgb: the pinned image this submit copies into (one of host_rgb) */
         hipEvent_t traced = nullptr, copied = nullptr;
         uint32_t width = 0, rows = 0;
     };
     std::vector<Slot> slots;
+    /* slots + 1 pinned images, used round-robin by submit number: the image handed out by eu_sequence_next stays untouched
+     * until the NEXT eu_sequence_next, however many frames are submitted in between */
+    std::vector<uint8_t *> host_rgb;
     unsigned long long submitted = 0, taken = 0;
 };
+
+static constexpr size_t SEQ_CNT_BYTES = 4096 * EU_TS_ROW * sizeof(unsigned long long);      /* >= sizeof(EuDevCounters); up to 4096 workgroup rows */
+static_assert(sizeof(EuDevCounters) <= SEQ_CNT_BYTES, "counter buffer");
 
 extern "C" void eu_sequence_destroy(eu_sequence *q) {
     if (!q) return;
@@ -615,11 +765,11 @@ extern "C" void eu_sequence_destroy(eu_sequence *q) {
         if (s.d_rgba) (void)hipFree(s.d_rgba);
         if (s.d_rgb) (void)hipFree(s.d_rgb);
         if (s.d_cnt) (void)hipFree(s.d_cnt);
-        if (s.h_rgb) (void)hipHostFree(s.h_rgb);
         if (s.h_cnt) (void)hipHostFree(s.h_cnt);
         if (s.traced) (void)hipEventDestroy(s.traced);
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
+    for (uint8_t *h : q->host_rgb) if (h) (void)hipHostFree(h);
     for (hipStream_t st : q->slot_stream) if (st) (void)hipStreamDestroy(st);
     if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     for (size_t k = 1; k < q->slot_renderer.size(); k++) eu_renderer_destroy(q->slot_renderer[k]);
@@ -651,12 +801,14 @@ extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t m
     for (auto &s : q->slots) {
         if ((e = hipMalloc((void **)&s.d_rgba, (size_t)q->max_pixels * 4)) != hipSuccess) return fail(e, "hipMalloc");
         if ((e = hipMalloc((void **)&s.d_rgb, (size_t)q->max_pixels * 3 + 16)) != hipSuccess) return fail(e, "hipMalloc");
-        if ((e = hipMalloc((void **)&s.d_cnt, sizeof(EuDevCounters))) != hipSuccess) return fail(e, "hipMalloc");
-        if ((e = hipHostMalloc((void **)&s.h_rgb, (size_t)q->max_pixels * 3 + 16, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-        if ((e = hipHostMalloc((void **)&s.h_cnt, sizeof(EuDevCounters), hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipMalloc((void **)&s.d_cnt, SEQ_CNT_BYTES)) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipHostMalloc((void **)&s.h_cnt, SEQ_CNT_BYTES, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
         if ((e = hipEventCreateWithFlags(&s.traced, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
     }
+    q->host_rgb.assign(slots + 1, nullptr);
+    for (auto &h : q->host_rgb)
+        if ((e = hipHostMalloc((void **)&h, (size_t)q->max_pixels * 3 + 16, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
     *out = q;
     return EU_OK;
 }
@@ -677,11 +829,16 @@ extern "C" int eu_sequence_submit(eu_sequence *q, const eu_camera *cam, const eu
     if (rc != EU_OK) { if (rs != r) r->err = rs->err; return rc; }
     rc = eu_pack_rgb_device(rs, s.d_rgba, s.d_rgb, pixels, trace_stream);
     if (rc != EU_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(s.d_cnt, rs->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToDevice, trace_stream));   /* this slot's next frame zeroes them */
+    /* this slot's next frame overwrites its renderer's counters */
+    s.cnt_rows = rs->ts_last ? rs->ts_grid_last : 0u;
+    if (s.cnt_rows > 4096) { r->err = "more workgroups than the sequence's counter rows"; return EU_ERR_CAPACITY; }
+    const size_t cnt_bytes = s.cnt_rows ? (size_t)s.cnt_rows * EU_TS_ROW * sizeof(unsigned long long) : sizeof(EuDevCounters);
+    HIP_TRY(hipMemcpyAsync(s.d_cnt, s.cnt_rows ? (const void *)rs->ts.wg_counters : (const void *)rs->d_counters, cnt_bytes, hipMemcpyDeviceToDevice, trace_stream));
     HIP_TRY(hipEventRecord(s.traced, trace_stream));
     HIP_TRY(hipStreamWaitEvent(q->copy_stream, s.traced, 0));
+    s.h_rgb = q->host_rgb[q->submitted % q->host_rgb.size()];
     HIP_TRY(hipMemcpyAsync(s.h_rgb, s.d_rgb, pixels * 3, hipMemcpyDeviceToHost, q->copy_stream));
-    HIP_TRY(hipMemcpyAsync(s.h_cnt, s.d_cnt, sizeof(EuDevCounters), hipMemcpyDeviceToHost, q->copy_stream));
+    HIP_TRY(hipMemcpyAsync(s.h_cnt, s.d_cnt, cnt_bytes, hipMemcpyDeviceToHost, q->copy_stream));
     HIP_TRY(hipEventRecord(s.copied, q->copy_stream));
     s.width = f->width; s.rows = rows;
     q->submitted++;
@@ -699,8 +856,14 @@ extern "C" int eu_sequence_next(eu_sequence *q, const uint8_t **rgb_host, uint32
     *rgb_host = s.h_rgb;
     if (width) *width = s.width;
     if (rows) *rows = s.rows;
-    if (stats) { stats->rays = s.h_cnt->rays; stats->bg_samples = s.h_cnt->bg_samples; stats->nan_pixels = s.h_cnt->nan_pixels; stats->errors = s.h_cnt->errors; }
-    if (s.h_cnt->overflow) { r->err = "wavefront queue overflow: raise EU_WF_RAY_FACTOR or render in row tiles"; return EU_ERR_CAPACITY; }
+    unsigned long long overflow = 0;
+    if (s.cnt_rows) ts_sum_rows((const unsigned long long *)s.h_cnt, s.cnt_rows, stats, &overflow);
+    else {
+        const EuDevCounters *hc = (const EuDevCounters *)s.h_cnt;
+        if (stats) { stats->rays = hc->rays; stats->bg_samples = hc->bg_samples; stats->nan_pixels = hc->nan_pixels; stats->errors = hc->errors; }
+        overflow = hc->overflow;
+    }
+    if (overflow) { r->err = "tree-node pool / ray queue overflow: raise EU_TS_NODE_FACTOR (EU_WF_RAY_FACTOR) or render in row tiles"; return EU_ERR_CAPACITY; }
     return EU_OK;
 }
 

@@ -30,6 +30,7 @@
 #include "flat_scene.h"
 
 #define EU_DEV __device__ __forceinline__
+#define EU_RPN_INLINE __device__ __noinline__
 #define EU_MAX_DEPTH 16
 #define EU_PI_C 3.14159265358979323846264338327950288
 #define EU_FRAC_PI_2_C 1.57079632679489661923132169163975144
@@ -56,16 +57,18 @@ struct EuDevCounters {      /* device memory, zeroed before each launch */
     unsigned long long phase[16];  /* diagnostic builds only */
     unsigned long long gen_count[EU_MAX_DEPTH + 2];   /* wavefront pipeline: rays queued per generation */
     unsigned long long overflow;                      /* rays / nodes dropped because a queue was full */
+    unsigned long long node_chunks;                   /* stream kernel: node chunks handed out so far */
 };
 
 /* ------------------------------------------------------------------ scene view */
 struct EuScene {
     const uint64_t *w;      /* blob (LDS or global) */
+    const uint64_t *wrt;    /* the blob in device memory: texel addresses are patched there at upload */
     uint32_t off_ops, off_params, off_entities, n_entities, off_materials, off_transforms, off_code;
     uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background, off_bounds;
 
     EU_DEV void init(const uint64_t *base) {
-        w = base;
+        w = base; wrt = base;
         const EuFlatHeader *h = (const EuFlatHeader *)base;
         off_ops = h->off_ops; off_params = h->off_params; off_entities = h->off_entities; n_entities = h->n_entities;
         off_materials = h->off_materials; off_transforms = h->off_transforms; off_code = h->off_code;
@@ -90,6 +93,7 @@ struct EuScene {
     EU_DEV const EuFlatSurface *surface(uint32_t s) const { return (const EuFlatSurface *)(w + off_surfaces + 8 * s); }
     EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
     EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
+    EU_DEV uint64_t texels(uint32_t m) const { return ((const EuFlatMapped *)(wrt + off_mapped + 8 * m))->texels; }
     EU_DEV const double *bounds(uint32_t b, int D) const { return (const double *)(w + off_bounds + (uint32_t)(D + 2) * b); }
     EU_DEV const uint8_t *perlin(uint32_t p) const { return (const uint8_t *)(w + off_perlin + 64 * p); }
 };
@@ -660,7 +664,7 @@ EU_DEV double pow_int(double x, double y) {   /* meval powf restricted to integr
     return (y < 0.0) ? 1.0 / r : r;
 }
 
-template <int D> __device__ __noinline__ double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
+template <int D> EU_RPN_INLINE double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
     uint32_t off = (uint32_t)prog, len = (uint32_t)(prog >> 32);
     double st[8];
     int sp = 0;
@@ -913,7 +917,7 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
     /* texels live in device (global) memory; the address comes out of the scene blob, so say so: a generic pointer would be
      * read with flat loads (vmcnt and lgkmcnt both) */
     typedef const uint32_t __attribute__((address_space(1))) *global_u32_ptr;
-    const global_u32_ptr tex = (global_u32_ptr)(uintptr_t)M->texels;
+    const global_u32_ptr tex = (global_u32_ptr)(uintptr_t)S.texels(id);
     if (M->tex_kind == EU_TEX_NEAREST) {                       /* surface.rs:434-451 */
         double x = floor(pu * M->wd), y = floor(pv * M->hd);
         uint32_t xi, yi;

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
+    __syncthreads();      /* the other waves' first append must not overtake the store above */
     EuScene S;
     S.init(scene_g);
     LaneCounters cnt = {0, 0, 0, 0};
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
+    __syncthreads();
     /* The hit entity differs from lane to lane, so the surface / colour-program records are read with per-lane
      * addresses: from a copy of the flat scene in LDS (the L1 is swept by the ray streams, a global read of the
      * scene usually goes to L2). */

@@ -224,8 +224,8 @@ class FrameSequence:
         self.in_flight += 1
 
     def next(self, copy=True):
-        """RawImage2d of the oldest frame in flight.  With copy=False `.data` aliases the pinned slot (valid until the slot
-        is reused, i.e. for `slots` further submits)."""
+        """RawImage2d of the oldest frame in flight.  With copy=False `.data` aliases a pinned image of the sequence, valid until
+        the NEXT call of next() (the sequence rotates slots + 1 images), however many frames are submitted in between."""
         ptr, w, rows, st = C.c_void_p(), C.c_uint32(), C.c_uint32(), _capi.Stats()
         rc = _capi.lib().eu_sequence_next(self._h, C.byref(ptr), C.byref(w), C.byref(rows), C.byref(st))
         if rc != _capi.EU_OK:

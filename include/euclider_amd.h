@@ -146,8 +146,9 @@ int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, in
  * The frame loop around Environment::render (simulation.rs:93-150): the reference finishes a frame, uploads it and only
  * then starts the next.  A sequence keeps up to `slots` frames in flight on its own streams: eu_sequence_submit queues
  * trace + RGB8 pack + an asynchronous copy into pinned host memory and returns at once; eu_sequence_next waits for the
- * OLDEST submitted frame and hands out its image (rows of the reference's RawImage2d, valid until `slots` further
- * submits) and its counters.  Frames may differ in size (the run-time `resolution` divisor, simulation.rs:284-306), time
+ * OLDEST submitted frame and hands out its image (rows of the reference's RawImage2d; the sequence owns slots + 1
+ * pinned images, so the one handed out stays valid until the NEXT eu_sequence_next, however many frames are submitted in
+ * between) and its counters.  Frames may differ in size (the run-time `resolution` divisor, simulation.rs:284-306), time
  * (time-varying surfaces) and camera.  Every slot traces on its own stream with its own work buffers and counters (the scene
  * and its textures are resident once per slot), so consecutive frames overlap on the GPU.  Do not interleave eu_render* calls
  * on the same renderer while frames are in flight. */

@@ -292,26 +292,26 @@ def test_8k_frame_on_one_gpu_in_bands():
         assert np.array_equal(rgb[0], full.data[y]), "row %d differs" % y
 
 
-def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
-    """With queues far too small for the frame (EU_WF_RAY_FACTOR), the asynchronous path reports EU_ERR_CAPACITY and the
-    synchronous eu_render still returns the right frame (traced again by the persistent stack-based kernel)."""
+def test_node_pool_overflow_is_reported_and_retried(monkeypatch):
+    """The stream kernel's ray queues cannot overflow; its tree-node pool can.  With a pool far too small for the frame
+    (EU_TS_NODE_FACTOR) the asynchronous path reports EU_ERR_CAPACITY and the synchronous eu_render still returns the
+    right frame (it enlarges the pool and traces the frame again)."""
     from euclider_amd import Parser, _capi
     path = os.path.join(SCENES, "3d_room.json")
     a = Parser().parse_file(path)
-    a.camera.max_depth = 4
+    a.camera.max_depth = 8
     good = a.render((1920, 1080))
     a.close()
-    monkeypatch.setenv("EU_WF_RAY_FACTOR", "0.05")
-    monkeypatch.setenv("EU_WF_STREAMS", "1")
-    b = Parser().parse_file(path)
-    b.camera.max_depth = 4
-    fell_back = b.render((1920, 1080))
-    assert np.array_equal(fell_back.data, good.data) and fell_back.stats == good.stats
+    monkeypatch.setenv("EU_TS_NODE_FACTOR", "0")
     from euclider_amd import FrameSequence
     from euclider_amd.environment import EuError
+    b = Parser().parse_file(path)
+    b.camera.max_depth = 8
     with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
         seq.submit((1920, 1080))
         with pytest.raises(EuError) as ei:
             seq.next()
         assert ei.value.code == _capi.EU_ERR_CAPACITY
+    retried = b.render((1920, 1080))
+    assert np.array_equal(retried.data, good.data) and retried.stats == good.stats
     b.close()

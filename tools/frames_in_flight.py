@@ -4,8 +4,10 @@ import torch
 from euclider_amd import Parser
 dev = torch.device("cuda", 0)
 n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-envs = [Parser().parse_file("scenes/3d_room.json") for _ in range(n_env)]
-for e in envs: e.camera.max_depth = 8
+scene = sys.argv[2] if len(sys.argv) > 2 else "3d_room.json"
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+envs = [Parser().parse_file("scenes/" + scene) for _ in range(n_env)]
+for e in envs: e.camera.max_depth = depth
 W, H = 1920, 1080
 streams = [torch.cuda.Stream(dev) for _ in range(n_env)]
 rgba = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(n_env)]
@@ -23,5 +25,5 @@ for k in range(K): step(k)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 rays = envs[0].stats()["rays"]
-print("envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
+print(scene, depth, "kernel", os.environ.get("EU_KERNEL", "stream"), "envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
 assert torch.equal(rgb[0][:H*W*3], rgb[-1][:H*W*3])
