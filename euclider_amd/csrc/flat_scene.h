@@ -33,7 +33,12 @@ enum EuShapeKind : uint32_t {
      * hypercuboid, wall sets), collapsed into ONE op: `count` leaves, parameters contiguous with
      * stride 2*D+2 (HALFSPACE layout; a Hyperplane is stored with signum = NaN, nflip = n).
      * Behaves like a leaf that produces up to `count` hits. */
-    EU_SH_CHAIN_UNION = 16, EU_SH_CHAIN_INTERSECTION = 17
+    EU_SH_CHAIN_UNION = 16, EU_SH_CHAIN_INTERSECTION = 17,
+    /* an Intersection chain of exactly 2*D half-spaces whose leaf k has the normal +-e_(k/2) exactly (components +-1 and
+     * +-0) and a finite non-zero constant: what HalfSpace3::cuboid / HalfSpace4::hypercuboid build (d3/entity/shape.rs:17-66).
+     * Same semantics as EU_SH_CHAIN_INTERSECTION; the device may replace every dot product with the normal by one
+     * multiplication (trace_device.h, chain_matrices_box). */
+    EU_SH_CHAIN_BOX = 18
 };
 #define EU_CHAIN_MAX 8
 enum EuMaterialKind : uint32_t { EU_MAT_VACUUM = 0, EU_MAT_LINEAR = 1 };

@@ -94,9 +94,10 @@ struct eu_renderer {
     bool have_timing = false;
     int num_cus = 0;
     bool scene_in_lds = true;
-    /* which kernels trace a frame: the persistent stream kernel (trace_stream.h) unless EU_KERNEL says otherwise */
+    /* which kernels trace a frame: the generation-synchronous wavefront pipeline (trace_wavefront.h) unless EU_KERNEL says
+     * otherwise ("stream": the persistent one-launch kernel of trace_stream.h, "mega": the stack-based kernel) */
     enum { PATH_STREAM = 0, PATH_WAVEFRONT = 1, PATH_MEGA = 2 };
-    int path = PATH_STREAM;
+    int path = PATH_WAVEFRONT;
     bool use_wavefront = true;               /* among the two older paths */
     /* stream kernel: per-workgroup ray chunks + the shared node pool, grown on demand */
     EuTsPool ts = {};
@@ -184,7 +185,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
         if (const char *k = getenv("EU_KERNEL")) {
             const std::string ks(k);
-            r->path = ks == "mega" ? eu_renderer::PATH_MEGA : (ks == "wavefront" ? eu_renderer::PATH_WAVEFRONT : eu_renderer::PATH_STREAM);
+            r->path = ks == "mega" ? eu_renderer::PATH_MEGA : (ks == "stream" ? eu_renderer::PATH_STREAM : eu_renderer::PATH_WAVEFRONT);
             r->use_wavefront = ks != "mega";
         }
         if (const char *k = getenv("EU_TS_NODE_FACTOR")) r->ts_node_factor = atof(k);

@@ -729,6 +729,22 @@ struct Flattener {
         return true;
     }
 
+    /* EU_SH_CHAIN_BOX: 2*D half-spaces, leaf k's normal is +-e_(k/2) exactly, its constant finite and non-zero */
+    bool is_axis_box(const std::vector<const Shape *> &chain) const {
+        if (no_box_chains() || (int)chain.size() != 2 * D) return false;
+        for (int k = 0; k < 2 * D; k++) {
+            const Shape &l = *chain[k];
+            if (l.kind != Shape::HalfSpace) return false;
+            for (int i = 0; i < D; i++) {
+                if (i == k / 2) { if (!(l.a[i] == 1.0 || l.a[i] == -1.0)) return false; }
+                else if (!(l.a[i] == 0.0)) return false;
+            }
+            if (!std::isfinite(l.r) || l.r == 0.0) return false;
+        }
+        return true;
+    }
+    static bool no_box_chains() { static const bool v = getenv("EU_NO_BOX_CHAINS") != nullptr; return v; }      /* A/B diagnostics */
+
     void push_halfspace_params(const Shape &s) {
         for (int i = 0; i < D; i++) params.push_back(s.a[i]);
         params.push_back(s.r);
@@ -752,6 +768,7 @@ struct Flattener {
         if (s.kind == Shape::ComposableShape && (s.operation == SetOperation::Union || s.operation == SetOperation::Intersection) &&
             collect_chain(s, s.operation, chain) && chain.size() >= 2 && chain.size() <= EU_CHAIN_MAX) {
             op.kind = (uint8_t)(s.operation == SetOperation::Union ? EU_SH_CHAIN_UNION : EU_SH_CHAIN_INTERSECTION);
+            if (s.operation == SetOperation::Intersection && is_axis_box(chain)) op.kind = EU_SH_CHAIN_BOX;
             op.count = (uint8_t)chain.size();
             op.param = (uint32_t)params.size();
             for (auto *leaf : chain) push_halfspace_params(*leaf);

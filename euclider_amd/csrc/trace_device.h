@@ -221,6 +221,30 @@ template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const d
 /* ---- half-space chains (EU_SH_CHAIN_*): all leaves of a left-fold Union / Intersection are planes ---- */
 #define EU_HS_STRIDE(D) (2 * (D) + 2)
 
+/* is_point_inside of an EU_SH_CHAIN_BOX (see chain_matrices_box for why one product replaces the dot product) */
+template <int D> EU_DEV bool chain_inside_box(const double *P, const double *p) {
+    bool finite = true;
+#pragma unroll
+    for (int m = 0; m < D; m++) finite = finite && __builtin_isfinite(p[m]);
+    bool acc = true;
+    if (finite) {
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * D; k++) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double r = Pk[k / 2] * p[k / 2] + Pk[D];
+            acc = acc && (Pk[D + 1] == rust_signum(r));
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * D; k++) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double r = vdot<D>(Pk, p) + Pk[D];
+            acc = acc && (Pk[D + 1] == rust_signum(r));
+        }
+    }
+    return acc;
+}
+
 template <int D> EU_DEV bool chain_inside(bool is_union, uint32_t n, const double *P, const double *p) {
     bool acc = !is_union;
 #pragma unroll
@@ -242,7 +266,9 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, cnt;
         S.op(i, kind, f, param, cnt);
-        if (kind >= EU_SH_CHAIN_UNION) {
+        if (kind == EU_SH_CHAIN_BOX) {
+            st = (st << 1) | (chain_inside_box<D>(S.params(param), p) ? 1ull : 0ull);
+        } else if (kind >= EU_SH_CHAIN_UNION) {
             st = (st << 1) | (chain_inside<D>(kind == EU_SH_CHAIN_UNION, cnt, S.params(param), p) ? 1ull : 0ull);
         } else if (kind < EU_SH_UNION) {
             st = (st << 1) | (leaf_inside<D>(kind, S.params(param), p) ? 1ull : 0ull);
@@ -307,8 +333,8 @@ struct Rgba { double r, g, b, a; };
  * single hit of leaf k, reproducing the iterator's three modes: both present (a failed test skips),
  * only a left (a failed test ends the stream), only b left. */
 template <int D>
-EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const double *o, const double *d,
-                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out) {
+EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const double *d,
+                           double (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
     /* Fully unrolled over the (at most 8) leaves with wave-uniform guards: the t_k and the hit points
      * stay in registers, plane parameters arrive through scalar loads (uniform addresses), and every
      * matrix entry costs one dot product, one compare and one bit insert. */
@@ -323,7 +349,7 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
             if (!(t < 0.0)) pres |= 1u << k;
         }
     }
-    uint32_t in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];     /* in_k[j] bit i: leaf j contains hit i ; lt_k[j] bit i: t_i < t_j */
+    /* in_k[j] bit i: leaf j contains hit i ; lt_k[j] bit i: t_i < t_j */
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
 #pragma unroll
@@ -343,6 +369,68 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
             }
         }
     }
+    pres_out = pres;
+}
+
+/* The same matrices for an EU_SH_CHAIN_BOX (leaf k: normal = s_k e_a with a = k/2, s_k = +-1, the other components +-0; constant
+ * c_k finite and non-zero).  The reference's dot product with such a normal, n . x = ((n_0 x_0 + n_1 x_1) + ...), is for a
+ * FINITE x a sum of signed zeros and the one term s_k x_a:
+ *   - x_a != 0: adding zeros does not change a non-zero value, and s_k x_a is exact: n . x == n_a * x_a, bit for bit;
+ *   - x_a == 0: n . x is a zero of some sign, and so is n_a * x_a; whatever the signs, adding c_k != 0 gives c_k exactly.
+ * So `n . x + c_k` (the numerator of t, shape.rs:789, and the is_point_inside value, shape.rs:877) equals `n_a * x_a + c_k`
+ * whenever x is finite.  The denominator of t, n . d, has no constant added: it is replaced only when d_a != 0.  A ray with a
+ * non-finite origin or direction (the NaN rays of the general_rotation quirk) or with some d_a == 0 (parallel to a face: the
+ * sign of the zero denominator decides between +inf and -inf) is not "regular" and never gets here (ray_is_regular); a
+ * non-finite hit point (t overflowed) makes this routine report false.  Either way the ray is traced by the generic routine.
+ * 7 (D = 3: 5) flops per dot product become 1. */
+template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < D; m++) ok = ok && __builtin_isfinite(o[m]) && __builtin_isfinite(d[m]) && d[m] != 0.0;
+    return ok;
+}
+
+template <int D>
+EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d,
+                               double (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
+    constexpr uint32_t n = 2 * D;
+    bool ok = true;         /* the caller has checked the ray itself (ray_is_regular) */
+    uint32_t pres = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
+        tk[k] = 0.0;
+        if (k < n) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const double t = -(Pk[k / 2] * o[k / 2] + Pk[D]) / (Pk[k / 2] * d[k / 2]);
+            tk[k] = t;
+            if (!(t < 0.0)) pres |= 1u << k;
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
+        if (i < n) {
+            double loc[D];
+#pragma unroll
+            for (int m = 0; m < D; m++) { loc[m] = o[m] + d[m] * tk[i]; ok = ok && __builtin_isfinite(loc[m]); }
+#pragma unroll
+            for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
+                if (j < n && j != i) {
+                    const double *Pj = P + j * EU_HS_STRIDE(D);
+                    const double r = Pj[j / 2] * loc[j / 2] + Pj[D];
+                    if (Pj[D + 1] == rust_signum(r)) in_k[j] |= 1u << i;
+                    if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
+                }
+            }
+        }
+    }
+    pres_out = pres;
+    return ok;
+}
+
+template <int D>
+EU_DEV uint32_t chain_merge(bool is_union, uint32_t n, uint32_t pres, const uint32_t (&in_k)[EU_CHAIN_MAX], const uint32_t (&lt_k)[EU_CHAIN_MAX], uint32_t &list_out) {
     uint32_t list = 0, len = (pres & 1u);
 #pragma unroll
     for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) {
@@ -373,6 +461,18 @@ EU_DEV uint32_t eval_chain(bool is_union, uint32_t n, const double *P, const dou
     }
     list_out = list;
     return len;
+}
+
+/* use_box (wave-uniform): an EU_SH_CHAIN_BOX goes through chain_matrices_box; a lane it cannot serve sets `fail` (its result is
+ * then meaningless) and the caller traces the wave's rays again with use_box = false, where a box is an ordinary Intersection chain. */
+template <int D>
+EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const double *P, const double *o, const double *d,
+                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out, bool use_box, bool &fail) {
+    uint32_t pres = 0, in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];
+    if (use_box && kind == EU_SH_CHAIN_BOX) {      /* wave-uniform */
+        if (!chain_matrices_box<D>(P, o, d, tk, pres, in_k, lt_k)) fail = true;
+    } else chain_matrices<D>(n, P, o, d, tk, pres, in_k, lt_k);
+    return chain_merge<D>(kind == EU_SH_CHAIN_UNION, n, pres, in_k, lt_k, list_out);
 }
 
 /* First element of a Union chain's stream without building the streams (trace_closest only looks at element 0,
@@ -458,7 +558,7 @@ template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o,
  * entity's stream and its first element (only that is used by trace_closest, universe/mod.rs:114). */
 template <int D, class HS>
 EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
-                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c) {
+                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c, bool use_box, bool &fail) {
     if (first == root) {   /* a bare leaf or chain: no list machinery */
         uint32_t kind, f, param, count;
         S.op(root, kind, f, param, count);
@@ -473,7 +573,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
                 if (q == 0) return 0u;
                 if (q > 0) { first_t = tf; first_c = root | (idx << 16); return 1u; }
             }
-            const uint32_t n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, Pc, o, d, tk, list);
+            const uint32_t n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
             if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
@@ -502,7 +602,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
             if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
             else if (!(Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)))
-                n = eval_chain<D>(kind == EU_SH_CHAIN_UNION, count, Pc, o, d, tk, list);
+                n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
             if (n) {
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
@@ -603,6 +703,13 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
     else if (unk & 1u) cnt.errors++;          /* element 0 itself is something the reference never finishes computing */
     return n;
+}
+
+template <int D, class HS>
+EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
+                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c) {
+    bool fail = false;
+    return eval_shape<D, HS>(S, first, root, o, d, hs, cnt, first_t, first_c, false, fail);
 }
 
 /* normal of the hit described by `code` at parameter t (recomputed from the leaf) */

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
 
 /* ------------------------------------------------------------------ trace_closest */
 template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
+__global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
                                                                       EuWfBuffers B, EuDevCounters *counters, double *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
@@ -325,10 +325,20 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
             }
             cnt.rays++;
             IS_STAMP(14);
-            /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
+            /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  A wave whose rays are
+             * all regular (finite, no zero direction component) evaluates box chains with one product per dot product
+             * (chain_matrices_box); should a lane then report a non-finite hit point, the wave's rays are traced once more the generic way. */
             bool have = false;
             double best_t = 0.0;
             uint32_t best_code = 0, best_ent = 0xffffffffu;
+            bool use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull;
+#ifdef EU_PROFILE_ISECT
+            use_box = false;
+#endif
+            for (;;) {
+            bool fail = false;
+            LaneCounters c1 = cnt;
+            have = false; best_t = 0.0; best_code = 0; best_ent = 0xffffffffu;
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuScene::EntityView E = S.entity(e);
                 if (E.surface < 0) continue;
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
 #ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
                 if (!(E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d))) {
                     double t = 0.0; uint32_t code = 0;
-                    const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
+                    const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
                     if (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -346,10 +356,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_intersect_kernel(const uint
 #else
                 if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
                 double t = 0.0; uint32_t code = 0;
-                const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
+                const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
 #endif
+            }
+            if (__ballot(fail) == 0ull) { cnt = c1; break; }
+            use_box = false;
             }
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;

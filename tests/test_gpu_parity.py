@@ -302,6 +302,7 @@ def test_node_pool_overflow_is_reported_and_retried(monkeypatch):
     a.camera.max_depth = 8
     good = a.render((1920, 1080))
     a.close()
+    monkeypatch.setenv("EU_KERNEL", "stream")
     monkeypatch.setenv("EU_TS_NODE_FACTOR", "0")
     from euclider_amd import FrameSequence
     from euclider_amd.environment import EuError
@@ -315,3 +316,45 @@ def test_node_pool_overflow_is_reported_and_retried(monkeypatch):
     retried = b.render((1920, 1080))
     assert np.array_equal(retried.data, good.data) and retried.stats == good.stats
     b.close()
+
+
+def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
+    """Wavefront pipeline: with queues far too small for the frame (EU_WF_RAY_FACTOR), the asynchronous path reports
+    EU_ERR_CAPACITY and the synchronous eu_render still returns the right frame (traced again by the stack-based kernel)."""
+    from euclider_amd import Parser, _capi
+    path = os.path.join(SCENES, "3d_room.json")
+    a = Parser().parse_file(path)
+    a.camera.max_depth = 4
+    good = a.render((1920, 1080))
+    a.close()
+    monkeypatch.setenv("EU_KERNEL", "wavefront")
+    monkeypatch.setenv("EU_WF_RAY_FACTOR", "0.05")
+    monkeypatch.setenv("EU_WF_STREAMS", "1")
+    b = Parser().parse_file(path)
+    b.camera.max_depth = 4
+    fell_back = b.render((1920, 1080))
+    assert np.array_equal(fell_back.data, good.data) and fell_back.stats == good.stats
+    from euclider_amd import FrameSequence
+    from euclider_amd.environment import EuError
+    with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
+        seq.submit((1920, 1080))
+        with pytest.raises(EuError) as ei:
+            seq.next()
+        assert ei.value.code == _capi.EU_ERR_CAPACITY
+    b.close()
+
+
+@pytest.mark.parametrize("scene,w,h,depth", CASES)
+def test_stream_kernel_parity(scene, w, h, depth, monkeypatch):
+    """The persistent stream kernel (EU_KERNEL=stream, trace_stream.h) against the oracle: the same bar as the default path."""
+    monkeypatch.setenv("EU_KERNEL", "stream")
+    test_scene_parity(scene, w, h, depth)
+
+
+def test_stream_kernel_partitions_and_single_pixel(monkeypatch):
+    monkeypatch.setenv("EU_KERNEL", "stream")
+    test_row_tiles_match_full_frame()
+    test_strip_partition_matches_full_frame(3, 100)
+    test_trace_screen_point_unquantised()
+    test_time_and_crosshair()
+    test_edge_cases()
