@@ -11,7 +11,12 @@ RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
           each rank traces its strips and packs them to RGB8, ONE RCCL gather collects them on
           rank 0, which restores row order (= the reference's RawImage2d).
 
-Prints one JSON line (rank 0).  `value` = rays of all ranks / max-over-ranks wall time.
+Prints one JSON line (rank 0).  `value` = rays of all ranks / max-over-ranks wall time.  At N = 1 the line also carries
+`cpu_baseline` (the oracle timed on this host), `parity` (the frame the timed run left in HBM compared byte for byte with the
+oracle's frame) and `other_configs` (BASELINE configs 3 and 4, 4d_cylinders and the 8K frame on one GPU, a few steps each);
+at N > 1 also `config5` (the 8K frame over the same ranks, strong scaling).  `python bench.py --gpus N` without a launcher
+starts the N ranks itself (torch.distributed.run as a child process); with a launcher, a WORLD_SIZE that differs from
+--gpus is an error.
 """
 import argparse
 import json
@@ -43,6 +48,7 @@ def parse_args():
                          "sequence driver, images read back to pinned host memory -- the PCIe-inclusive rate")
     ap.add_argument("--slots", type=int, default=2, help="--animate: frames in flight")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
+    ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short runs of BASELINE configs 3, 4 and the 8K frame")
     return ap.parse_args()
 
 
@@ -71,8 +77,19 @@ def host_threads():
     return max(1, min(n, 64))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene_path, w, h, depth, sample_rows):
-    """The oracle (CPU restatement, kind "port") timed on this host's cores -- a reported baseline."""
+    """The oracle (CPU restatement, kind "port") timed on this host's cores -- a reported baseline.  Also returns the
+    oracle's frame (or row band) so that the GPU frame of the timed run can be compared with it."""
     from oracle.scene_loader import load_scene_file
     threads = host_threads()
     osc = load_scene_file(scene_path)
@@ -85,7 +102,7 @@ def cpu_baseline(scene_path, w, h, depth, sample_rows):
         rows = None
         sample = "%s %dx%d depth %d, whole frame, best of %d runs after 1 warm-up" % (os.path.basename(scene_path), w, h, depth, runs)
     t0 = time.perf_counter()
-    _, _, st = osc.render(w, h, max_depth=depth, threads=threads, rows=rows)        # warm-up (also bounds the cost)
+    orgb, _, st = osc.render(w, h, max_depth=depth, threads=threads, rows=rows)     # warm-up (also bounds the cost)
     first = time.perf_counter() - t0
     dt = first
     if first < 10.0:
@@ -95,8 +112,8 @@ def cpu_baseline(scene_path, w, h, depth, sample_rows):
             dt = min(dt, time.perf_counter() - t0)
     else:
         sample = sample.replace("best of %d runs after 1 warm-up" % runs, "1 run")
-    return {"value": st["rays"] / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds": round(dt, 3), "rays": st["rays"]}
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "host_threads_total": os.cpu_count(), "sample": sample, "seconds": round(dt, 3), "rays": st["rays"]}, orgb, rows, st
 
 
 def load_pmc(workload_key):
@@ -170,14 +187,66 @@ def animate(args, env, scene_path):
     print(json.dumps(out), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (before anything here
+    has touched the GPU) and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def other_configs(torch, dev, stream, Parser):
+    """BASELINE.json configs 3 and 4, the extra 4-D scene and the 8K frame on one GPU: a few steps each, so that the driver's
+    record carries them too.  Same timing rule as the headline (device-resident, synchronised on both sides)."""
+    out = []
+    for scene, W, H, depth, steps in (("3d_hallways.json", 1920, 1080, 12, 5), ("4d_frame.json", 1920, 1080, 8, 5),
+                                      ("4d_cylinders.json", 1920, 1080, 8, 3), ("3d_room.json", 7680, 4320, 8, 2)):
+        env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
+        env.camera.max_depth = depth
+        frame = env.frame(W, H, time=0.0, rows=(0, H))
+        rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        rgb = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
+
+        def step():
+            env.render_device(frame, rgba.data_ptr(), None, stream, device=dev.index)
+            env.pack_rgb_device(rgba.data_ptr(), rgb.data_ptr(), H * W, stream, device=dev.index)
+        step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        st = env.stats(device=dev.index)
+        kms = env.kernel_ms_history(steps, device=dev.index)
+        kernel_ms = sum(kms) / max(1, len(kms))
+        alg = 4.0 * W * H + 16.0 * st["bg_samples"] + env.info.flat_bytes
+        ach = alg / (kernel_ms * 1e-3) / 1e9
+        out.append({"workload": "%s %dx%d depth %d" % (scene, W, H, depth), "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
+                    "ms_per_step": dt * 1e3, "steps": steps, "rays_per_frame": int(st["rays"]),
+                    "would_panic_events": int(st["nan_pixels"] + st["errors"]),
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth))}})
+        env.close()
+        del rgba, rgb
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
-    if world != n and world != 1:
-        n = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line for "
+                         "a different N" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -207,80 +276,89 @@ def main():
         animate(args, env, scene_path)
         env.close()
         return
-    W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
-    strips = (rank, world) if world > 1 else None
-    frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
-    local_rows = env.local_rows(frame)
-    if world > 1:      # equal counts for the gather: pad to the largest rank
-        t = torch.tensor([local_rows], device=torch.device("cpu") if smoke_gloo else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        max_rows = int(t.item())
-    else:
-        max_rows = local_rows
-
-    rgba = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    gathered = None
-    allbuf = None
-    perm = None
-    full = None
-    rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
-    rgb_local = None
-    if world > 1:
-        # every rank packs its own strips to RGB8 before the gather (3 bytes per pixel travel, not 4; the root only reorders rows)
-        rgb_local = torch.empty((max_rows, W * 3), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            allbuf = torch.empty((world * max_rows, W * 3), dtype=torch.uint8, device=dev)   # the gather lands in place: no concatenation
-            gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
-            from euclider_amd.partition import gather_permutation
-            perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
-            full = rgb_out[:H * W * 3].view(H, W * 3)
-
-    def step():
-        env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
-        if world > 1:
-            env.pack_rgb_device(rgba.data_ptr(), rgb_local.data_ptr(), max_rows * W, stream, device=local_rank)
-            if smoke_gloo:                                          # one-GPU rehearsal only (see above)
-                torch.cuda.synchronize(dev)
-                host = rgb_local.cpu()
-                hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, hg, dst=0)
-                if rank == 0:
-                    for k in range(world):
-                        gathered[k].copy_(hg[k])
-            else:
-                dist.gather(rgb_local, gathered, dst=0)             # the single RCCL gather
-            if rank == 0:
-                torch.index_select(allbuf, 0, perm, out=full)       # rows back in frame order = the RawImage2d
+    def timed_run(W, H, steps, warmup):
+        """K steps of the partitioned frame (this rank's strips traced, packed, gathered on rank 0, rows restored), timed
+        between barriers + device synchronisation; returns max-over-ranks wall time and summed counters."""
+        strips = (rank, world) if world > 1 else None
+        frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
+        local_rows = env.local_rows(frame)
+        if world > 1:      # equal counts for the gather: pad to the largest rank
+            t = torch.tensor([local_rows], device=torch.device("cpu") if smoke_gloo else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            max_rows = int(t.item())
         else:
-            env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
-
-    def sync():
-        torch.cuda.synchronize(dev)
+            max_rows = local_rows
+        rgba = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        gathered = allbuf = perm = full = rgb_local = None
+        rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            # every rank packs its own strips to RGB8 before the gather (3 bytes per pixel travel, not 4; the root only reorders rows)
+            rgb_local = torch.empty((max_rows, W * 3), dtype=torch.uint8, device=dev)
+            if rank == 0:
+                allbuf = torch.empty((world * max_rows, W * 3), dtype=torch.uint8, device=dev)   # the gather lands in place: no concatenation
+                gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
+                from euclider_amd.partition import gather_permutation
+                perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
+                full = rgb_out[:H * W * 3].view(H, W * 3)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
+        def step():
+            env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
+            if world > 1:
+                env.pack_rgb_device(rgba.data_ptr(), rgb_local.data_ptr(), max_rows * W, stream, device=local_rank)
+                if smoke_gloo:                                          # one-GPU rehearsal only (see above)
+                    torch.cuda.synchronize(dev)
+                    host = rgb_local.cpu()
+                    hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, hg, dst=0)
+                    if rank == 0:
+                        for k in range(world):
+                            gathered[k].copy_(hg[k])
+                else:
+                    dist.gather(rgb_local, gathered, dst=0)             # the single RCCL gather
+                if rank == 0:
+                    torch.index_select(allbuf, 0, perm, out=full)       # rows back in frame order = the RawImage2d
+            else:
+                env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
 
-    st = env.stats(device=local_rank)
-    kms = env.kernel_ms_history(min(args.steps, 64), device=local_rank)
-    rdev = torch.device("cpu") if smoke_gloo else dev
-    tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=rdev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays_per_step = tot[0].item()
-    elapsed = tmax.item()
+        def sync():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
+        for _ in range(warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        st = env.stats(device=local_rank)
+        kms = env.kernel_ms_history(min(steps, 64), device=local_rank)
+        rdev = torch.device("cpu") if smoke_gloo else dev
+        tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=rdev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return {"W": W, "H": H, "elapsed": tmax.item(), "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
+                "local_rows": local_rows, "rgb_out": rgb_out, "steps": steps}
+
+    W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
+    run = timed_run(W, H, args.steps, args.warmup)
+    elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
+    tot = [run["rays"], 0.0, run["panic"]]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    cfg5 = None
+    if world > 1 and not args.fixed_frame:      # BASELINE config 5 next to the weak-scaling value: the 8K frame over the same ranks (strong scaling)
+        r5 = timed_run(7680, 4320, 3, 1)
+        cfg5 = {"workload": "%s 7680x4320 depth %d, %d ranks" % (args.scene, args.max_depth, world), "scaling": "strong",
+                "value": r5["rays"] * r5["steps"] / r5["elapsed"] / 1e6, "unit": "Mray/s", "ms_per_step": r5["elapsed"] / r5["steps"] * 1e3,
+                "steps": r5["steps"], "rays_per_frame": int(r5["rays"])}
+        del r5
     if rank == 0 and os.environ.get("EU_BENCH_DUMP"):
         import numpy as np
         np.save(os.environ["EU_BENCH_DUMP"], rgb_out[:H * W * 3].cpu().numpy().reshape(H, W, 3))
@@ -299,7 +377,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
-                       "would_panic_events": int(tot[2].item()),
+                       "would_panic_events": int(tot[2]),
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
                        "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -307,9 +385,23 @@ def main():
                          "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms),
                          "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it"},
         }
+        if cfg5 is not None:
+            out["config5"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows)
-            out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            import numpy as np
+            cb, orgb, rows, ost = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows)
+            out["cpu_baseline"] = cb
+            out["config"]["gpu_over_cpu"] = value / cb["value"]
+            # the frame the timed run left in HBM against the oracle's frame of the same inputs (whole frame unless --cpu-sample-rows)
+            gpu_rgb = rgb_out[:H * W * 3].cpu().numpy().reshape(H, W, 3)
+            if rows is not None:
+                gpu_rgb = gpu_rgb[rows[0]:rows[1]]
+            out["parity"] = {"bytes_compared": int(orgb.size), "mismatch": int((gpu_rgb != orgb).sum()),
+                             "rays_equal": (rows is None and int(st["rays"]) == int(ost["rays"])) if rows is None else None,
+                             "checked_against": "oracle/ (CPU restatement), same scene, camera, frame"}
+        if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json":
+            del rgb_out
+            out["other_configs"] = other_configs(torch, dev, stream, Parser)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

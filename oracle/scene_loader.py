@@ -144,6 +144,22 @@ def ivec(vals):
     return (C.c_int * max(1, len(vals)))(*vals)
 
 
+def default_threads():
+    """Threads a render uses when the caller does not say: the cgroup CPU quota / affinity mask, at most 64."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 class ParserError(Exception):
     """Mirrors scene.rs:524-552 (kind is one of the ParserError variants)."""
 
@@ -449,7 +465,7 @@ class OracleScene:
         rgb = np.zeros(((r1 - r0), width, 3), dtype=np.uint8)
         hit = np.zeros(((r1 - r0), width), dtype=np.float64) if want_hit_t else None
         st = Stats()
-        threads = threads or os.cpu_count() or 1
+        threads = threads or default_threads()
         rc = self.L.eo_render(self.s, C.byref(cam), C.byref(fr), threads, rgb.ctypes.data,
                               hit.ctypes.data if hit is not None else None, C.byref(st))
         if rc != 0:
