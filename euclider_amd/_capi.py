@@ -95,6 +95,11 @@ SYMBOLS = {
     "eu_sequence_submit": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame)]),
     "eu_sequence_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(Stats)]),
+    "eu_multi_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "eu_multi_destroy": (None, [C.c_void_p]),
+    "eu_render_multi": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_void_p),
+                                  C.POINTER(Stats)]),
+    "eu_multi_error": (C.c_char_p, [C.c_void_p]),
     "eu_trace_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "eu_camera_update": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Input)]),

@@ -868,6 +868,170 @@ extern "C" int eu_sequence_next(eu_sequence *q, const uint8_t **rgb_host, uint32
     return EU_OK;
 }
 
+
+/* ------------------------------------------------------------------ one frame across the GPUs of a node, from one process
+ * (scope row e; BASELINE config 5).  The frame's rows are cut into 8-row strips dealt round-robin over the devices
+ * (eu_frame.strip_*): glass objects, which cost hundreds of rays per pixel, are spread over all GPUs.  Every device traces
+ * its strips and packs them to RGB8 on its own stream; the packed strips travel to the root device over xGMI
+ * (hipMemcpyPeerAsync on the sending device's stream: one transfer per device per frame, landing in place in one buffer);
+ * a kernel on the root restores row order = the reference's RawImage2d (universe/mod.rs:351-356).  No other exchange. */
+__global__ void eu_restore_rows_kernel(const uint8_t *__restrict__ gathered, uint8_t *__restrict__ out, uint32_t width, uint32_t row_begin, uint32_t rows,
+                                       uint32_t n_dev, size_t dev_stride) {
+    /* output row y (of the rows [row_begin, row_begin + rows)): strip s = y / 8 belongs to device s % n at local row (s / n) * 8 + y % 8 */
+    const uint32_t y = blockIdx.y;
+    if (y >= rows) return;
+    const uint32_t s8 = y >> 3, k = s8 % n_dev, local = (s8 / n_dev) * 8 + (y & 7);
+    const size_t row_bytes = (size_t)width * 3;
+    const uint8_t *src = gathered + (size_t)k * dev_stride + (size_t)local * row_bytes;
+    uint8_t *dst = out + (size_t)y * row_bytes;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < row_bytes; b += (size_t)gridDim.x * blockDim.x) dst[b] = src[b];
+    (void)row_begin;
+}
+
+struct eu_multi {
+    std::vector<eu_renderer *> r;            /* r[k] on devices[k]; r[0] is the root */
+    std::vector<int> devices;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> sent;
+    std::vector<uint32_t *> d_rgba;          /* per device: its strips, RGBA8 */
+    std::vector<uint8_t *> d_rgb;            /* per device (k > 0): its strips packed to RGB8 */
+    std::vector<size_t> cap_pixels;
+    uint8_t *d_gathered = nullptr;           /* root: n * max_rows * width * 3 */
+    uint8_t *d_out = nullptr;                /* root: rows * width * 3, frame order */
+    size_t gathered_bytes = 0, out_bytes = 0;
+    std::string err;
+};
+
+extern "C" void eu_multi_destroy(eu_multi *m) {
+    if (!m) return;
+    for (size_t k = 0; k < m->r.size(); k++) {
+        (void)hipSetDevice(m->devices[k]);
+        if (k < m->stream.size() && m->stream[k]) { (void)hipStreamSynchronize(m->stream[k]); (void)hipStreamDestroy(m->stream[k]); }
+        if (k < m->sent.size() && m->sent[k]) (void)hipEventDestroy(m->sent[k]);
+        if (k < m->d_rgba.size() && m->d_rgba[k]) (void)hipFree(m->d_rgba[k]);
+        if (k < m->d_rgb.size() && m->d_rgb[k]) (void)hipFree(m->d_rgb[k]);
+        if (m->r[k]) eu_renderer_destroy(m->r[k]);
+    }
+    if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+    if (m->d_gathered) (void)hipFree(m->d_gathered);
+    if (m->d_out) (void)hipFree(m->d_out);
+    delete m;
+}
+
+extern "C" int eu_multi_create(const eu_scene *scene, const int *devices, int n_devices, eu_multi **out, char *err, size_t errlen) {
+    if (!scene || !devices || !out || n_devices < 1 || n_devices > 64) return EU_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    eu_multi *m = new eu_multi();
+    m->devices.assign(devices, devices + n_devices);
+    m->r.assign(n_devices, nullptr); m->stream.assign(n_devices, nullptr); m->sent.assign(n_devices, nullptr);
+    m->d_rgba.assign(n_devices, nullptr); m->d_rgb.assign(n_devices, nullptr); m->cap_pixels.assign(n_devices, 0);
+    for (int k = 0; k < n_devices; k++) {
+        int rc = eu_renderer_create(scene, devices[k], &m->r[k], err, errlen);
+        if (rc != EU_OK) { eu_multi_destroy(m); return rc; }
+        hipError_t e = hipSetDevice(devices[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->sent[k], hipEventDisableTiming);
+        if (e != hipSuccess) { set_err(err, errlen, std::string("eu_multi_create: ") + hipGetErrorString(e)); eu_multi_destroy(m); return EU_ERR_HIP; }
+        if (k > 0 && devices[k] != devices[0]) {      /* direct xGMI transfers where the topology allows them (otherwise the runtime stages the copy) */
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    }
+    *out = m;
+    return EU_OK;
+}
+
+#define MULTI_TRY(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            m->err = std::string(#expr) + ": " + hipGetErrorString(e_);                   \
+            return EU_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+extern "C" int eu_render_multi(eu_multi *m, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats) {
+    if (!m || !cam || !f) return EU_ERR_INVALID_ARGUMENT;
+    if (f->width == 0 || f->height == 0 || f->row_begin > f->row_end || f->row_end > f->height || f->strip_count > 1) return EU_ERR_INVALID_ARGUMENT;
+    const uint32_t n = (uint32_t)m->r.size(), rows = f->row_end - f->row_begin, W = f->width;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (rows == 0) return EU_OK;
+    const size_t row_bytes = (size_t)W * 3;
+    uint32_t max_rows = 0;
+    std::vector<eu_frame> fr(n, *f);
+    std::vector<uint32_t> lrows(n, 0);
+    for (uint32_t k = 0; k < n; k++) {
+        fr[k].strip_count = n; fr[k].strip_index = k;
+        lrows[k] = n > 1 ? eu_frame_local_rows(&fr[k]) : rows;
+        if (n == 1) { fr[k].strip_count = 0; fr[k].strip_index = 0; }
+        if (lrows[k] > max_rows) max_rows = lrows[k];
+    }
+    const size_t dev_stride = (size_t)max_rows * row_bytes;
+    /* buffers, grown on demand */
+    MULTI_TRY(hipSetDevice(m->devices[0]));
+    if (m->gathered_bytes < dev_stride * n + 16) {
+        if (m->d_gathered) (void)hipFree(m->d_gathered);
+        m->d_gathered = nullptr; m->gathered_bytes = 0;
+        MULTI_TRY(hipMalloc((void **)&m->d_gathered, dev_stride * n + 16));
+        m->gathered_bytes = dev_stride * n + 16;
+    }
+    if (m->out_bytes < (size_t)rows * row_bytes + 16) {
+        if (m->d_out) (void)hipFree(m->d_out);
+        m->d_out = nullptr; m->out_bytes = 0;
+        MULTI_TRY(hipMalloc((void **)&m->d_out, (size_t)rows * row_bytes + 16));
+        m->out_bytes = (size_t)rows * row_bytes + 16;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        const size_t pixels = (size_t)max_rows * W;
+        if (m->cap_pixels[k] < pixels) {
+            MULTI_TRY(hipSetDevice(m->devices[k]));
+            if (m->d_rgba[k]) (void)hipFree(m->d_rgba[k]);
+            if (m->d_rgb[k]) (void)hipFree(m->d_rgb[k]);
+            m->d_rgba[k] = nullptr; m->d_rgb[k] = nullptr; m->cap_pixels[k] = 0;
+            MULTI_TRY(hipMalloc((void **)&m->d_rgba[k], pixels * 4));
+            if (k > 0) MULTI_TRY(hipMalloc((void **)&m->d_rgb[k], pixels * 3 + 16));
+            m->cap_pixels[k] = pixels;
+        }
+    }
+    /* trace + pack everywhere, then one transfer per device into its slot of the root's buffer */
+    for (uint32_t k = 0; k < n; k++) {
+        if (lrows[k] == 0) continue;
+        MULTI_TRY(hipSetDevice(m->devices[k]));
+        int rc = render_device_impl(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, nullptr);
+        if (rc != EU_OK) { m->err = m->r[k]->err; return rc; }
+        uint8_t *packed = k == 0 ? m->d_gathered : m->d_rgb[k];      /* the root packs straight into slot 0 */
+        rc = eu_pack_rgb_device(m->r[k], m->d_rgba[k], packed, (size_t)lrows[k] * W, m->stream[k]);
+        if (rc != EU_OK) { m->err = m->r[k]->err; return rc; }
+        if (k > 0) MULTI_TRY(hipMemcpyPeerAsync(m->d_gathered + (size_t)k * dev_stride, m->devices[0], packed, m->devices[k], (size_t)lrows[k] * row_bytes, m->stream[k]));
+        MULTI_TRY(hipEventRecord(m->sent[k], m->stream[k]));
+    }
+    MULTI_TRY(hipSetDevice(m->devices[0]));
+    for (uint32_t k = 1; k < n; k++) if (lrows[k]) MULTI_TRY(hipStreamWaitEvent(m->stream[0], m->sent[k], 0));
+    if (n > 1) {
+        unsigned gx = (unsigned)((row_bytes + 255) / 256); if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(eu_restore_rows_kernel, dim3(gx, rows), dim3(256), 0, m->stream[0], m->d_gathered, m->d_out, W, f->row_begin, rows, n, dev_stride);
+        MULTI_TRY(hipGetLastError());
+    }
+    uint8_t *result = n > 1 ? m->d_out : m->d_gathered;
+    if (rgb_host) MULTI_TRY(hipMemcpyAsync(rgb_host, result, (size_t)rows * row_bytes, hipMemcpyDeviceToHost, m->stream[0]));
+    MULTI_TRY(hipStreamSynchronize(m->stream[0]));
+    if (rgb_dev_root) *rgb_dev_root = result;
+    int worst = EU_OK;
+    for (uint32_t k = 0; k < n; k++) {
+        if (lrows[k] == 0) continue;
+        eu_stats st;
+        const int rc = eu_renderer_stats(m->r[k], &st);
+        if (rc != EU_OK) { m->err = m->r[k]->err; worst = rc; continue; }
+        if (stats) { stats->rays += st.rays; stats->bg_samples += st.bg_samples; stats->nan_pixels += st.nan_pixels; stats->errors += st.errors; }
+    }
+    return worst;
+}
+
+extern "C" const char *eu_multi_error(const eu_multi *m) { return m ? m->err.c_str() : ""; }
+
 /* Universe::trace_path_unknown (universe/mod.rs:273-286) on the resident scene: one lane, synchronous. */
 extern "C" int eu_trace_path(eu_renderer *r, const double location[4], const double direction[4], double distance,
                              double out_location[4], double out_direction[4], int32_t *found) {

@@ -69,6 +69,9 @@ class Environment:
     # -- lifetime
     def close(self):
         L = _capi.lib()
+        for m in getattr(self, "_multis", {}).values():
+            L.eu_multi_destroy(m)
+        self._multis = {}
         for r in self._renderers.values():
             L.eu_renderer_destroy(r)
         self._renderers = {}
@@ -163,6 +166,35 @@ class Environment:
         img = RawImage2d(rgb, bw, nrows)
         img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
         img.hit_t = hit
+        return img
+
+    def render_multi(self, dimensions, devices, time=0.0, context=None, rows=None):
+        """Environment::render with the frame's 8-row strips dealt round-robin over `devices` (eu_render_multi: one
+        process, one renderer per listed device, packed strips gathered on devices[0], row order restored there)."""
+        context = context or SimulationContext()
+        width, height = dimensions
+        bw, bh = width // context.resolution, height // context.resolution
+        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, None)
+        key = tuple(int(d) for d in devices)
+        L = _capi.lib()
+        if not hasattr(self, "_multis"):
+            self._multis = {}
+        if key not in self._multis:
+            out = C.c_void_p()
+            err = C.create_string_buffer(512)
+            arr = (C.c_int * len(key))(*key)
+            rc = L.eu_multi_create(self._scene, arr, len(key), C.byref(out), err, len(err))
+            if rc != _capi.EU_OK:
+                raise EuError(rc, err.value.decode())
+            self._multis[key] = out
+        nrows = fr.row_end - fr.row_begin
+        rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
+        st = _capi.Stats()
+        rc = L.eu_render_multi(self._multis[key], C.byref(self.camera), C.byref(fr), rgb.ctypes.data, None, C.byref(st))
+        if rc != _capi.EU_OK:
+            raise EuError(rc, L.eu_multi_error(self._multis[key]).decode())
+        img = RawImage2d(rgb, bw, nrows)
+        img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
         return img
 
     def render_device(self, frame, rgba_ptr, hit_t_ptr=None, stream=None, device=0, camera=None):

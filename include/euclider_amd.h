@@ -157,6 +157,21 @@ void eu_sequence_destroy(eu_sequence *);
 int eu_sequence_submit(eu_sequence *, const eu_camera *, const eu_frame *);
 int eu_sequence_next(eu_sequence *, const uint8_t **rgb_host, uint32_t *width, uint32_t *rows, eu_stats *);
 
+/* ---- one frame across the GPUs of a node (scope row e, BASELINE config 5) ------------------------------
+ * the frame's rows [row_begin,row_end) are cut into 8-row strips dealt round-robin over `devices`
+ * (the partition eu_frame.strip_* describes); every device traces and packs its strips, the packed strips travel to
+ * devices[0] over xGMI (one peer transfer per device per frame, landing in place), and a kernel there restores row order =
+ * the reference's RawImage2d (universe/mod.rs:351-356).  One process drives all devices: this is what a Rust
+ * `impl Environment` (simulation.rs:86 holds a single Box<Environment>) calls to reach 8 GPUs.  The same device may be listed
+ * more than once (then its renderers share it).  `f->strip_count` must be 0: the partition is this call's business.
+ * rgb_host (optional): rows*width*3 bytes, frame order.  rgb_dev_root (optional): receives the DEVICE address (on
+ * devices[0]) of the same image, valid until the next call.  stats: summed over the devices. */
+typedef struct eu_multi eu_multi;
+int eu_multi_create(const eu_scene *, const int *devices, int n_devices, eu_multi **out, char *err, size_t errlen);
+void eu_multi_destroy(eu_multi *);
+int eu_render_multi(eu_multi *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats);
+const char *eu_multi_error(const eu_multi *);
+
 /* ---- camera motion ("next" row f3 of the scope table) ------------------------------------------------
  * Universe::trace_path_unknown (universe/mod.rs:273-286): push a point `distance` along `direction`
  * through surfaces and materials (portals rescale the step; get_path surface.rs:164-197).  Runs on the

@@ -359,3 +359,25 @@ def test_stream_kernel_partitions_and_single_pixel(monkeypatch):
     test_trace_screen_point_unquantised()
     test_time_and_crosshair()
     test_edge_cases()
+
+
+@pytest.mark.parametrize("ranks,W,H,rows", [(2, 160, 90, None), (3, 200, 100, None), (8, 96, 64, None), (2, 160, 90, (13, 77))])
+def test_render_multi_on_one_device(ranks, W, H, rows):
+    """eu_render_multi (config 5's path through the C ABI) with several renderers on the ONE device of this box: every
+    renderer traces its own strips with the HIP path, the packed strips are gathered into the root's buffer and the row
+    order is restored by the kernel -- the product's multi-GPU code, end to end, against the single-renderer frame and
+    (for one case) the oracle."""
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, "3d_room.json")
+    env = Parser().parse_file(path)
+    env.camera.max_depth = 6
+    one = env.render((W, H), rows=rows)
+    multi = env.render_multi((W, H), [0] * ranks, rows=rows)
+    again = env.render_multi((W, H), [0] * ranks, rows=rows)
+    env.close()
+    assert np.array_equal(multi.data, one.data) and multi.stats == one.stats
+    assert np.array_equal(again.data, one.data)
+    if ranks == 2 and rows is None:
+        orgb, _, ost = load_scene_file(path).render(W, H, max_depth=6)
+        assert np.array_equal(multi.data, orgb) and multi.stats["rays"] == ost["rays"]
