@@ -130,9 +130,52 @@ void eo_scene_free(eo_scene *s) {
 }
 const char *eo_last_error(const eo_scene *s) { return s->err; }
 
+/* ------------------------------------------------------------------ flop accounting (-DEO_COUNT_FLOPS builds only)
+ * f64 operations of the reference ALGORITHM per ray, counted where this restatement performs them: FL = add /
+ * subtract / multiply (1 each; negation, abs, floor, compares and selects are not counted), FLD = divide (and fmod), FLS = sqrt,
+ * FLT = calls of acos / asin / sin / cos / tan / atan / atan2.  The counters are thread-local and summed into eo_stats.flops[4]
+ * by eo_render; the shipped oracle (the timed CPU baseline) is built without them. */
+#ifdef EO_USE_LIBM      /* variant build: the platform libm (what Rust's f64::acos etc. call) instead of eo_math.h -- measures how far
+                         * a <= 1 ulp difference in the elementary functions moves the rendered bytes (tests/test_oracle_libm.py) */
+#define eo_acos acos
+#define eo_asin asin
+#define eo_sin sin
+#define eo_cos cos
+#define eo_tan tan
+#define eo_atan atan
+#define eo_atan2 atan2
+#endif
+static unsigned long long eo_fl_total[4];
+static pthread_mutex_t eo_fl_mu = PTHREAD_MUTEX_INITIALIZER;
+#ifdef EO_COUNT_FLOPS
+static __thread unsigned long long eo_fl[4];
+#define FL(n) (eo_fl[0] += (unsigned long long)(n))
+#define FLD(n) (eo_fl[1] += (unsigned long long)(n))
+#define FLS(n) (eo_fl[2] += (unsigned long long)(n))
+#define FLT(n) (eo_fl[3] += (unsigned long long)(n))
+static inline double eo_cnt_t_(double v) { FLT(1); return v; }
+static inline double eo_cnt_s_(double v) { FLS(1); return v; }
+static inline double eo_cnt_d_(double v) { FLD(1); return v; }
+#define eo_acos(x) eo_cnt_t_(eo_acos(x))
+#define eo_asin(x) eo_cnt_t_(eo_asin(x))
+#define eo_sin(x) eo_cnt_t_(eo_sin(x))
+#define eo_cos(x) eo_cnt_t_(eo_cos(x))
+#define eo_tan(x) eo_cnt_t_(eo_tan(x))
+#define eo_atan(x) eo_cnt_t_(eo_atan(x))
+#define eo_atan2(y, x) eo_cnt_t_(eo_atan2(y, x))
+#define sqrt(x) eo_cnt_s_(sqrt(x))
+#define fmod(x, y) eo_cnt_d_(fmod(x, y))
+#else
+#define FL(n) ((void)0)
+#define FLD(n) ((void)0)
+#define FLS(n) ((void)0)
+#define FLT(n) ((void)0)
+#endif
+
 /* ------------------------------------------------------------------ vectors (nalgebra 0.8.2) */
 /* dot / norm summation order x -> w (UNVERIFIED for nalgebra 0.8.2) */
 static double v_dot(int D, const double *a, const double *b) {
+    FL(2 * D - 1);
     double s = a[0] * b[0];
     for (int i = 1; i < D; i++) s = s + a[i] * b[i];
     return s;
@@ -141,14 +184,16 @@ static double v_nsq(int D, const double *a) { return v_dot(D, a, a); }
 static double v_norm(int D, const double *a) { return sqrt(v_nsq(D, a)); }
 static void v_normalize(int D, const double *a, double *out) {       /* v / |v| */
     double n = v_norm(D, a);
+    FLD(D);
     for (int i = 0; i < D; i++) out[i] = a[i] / n;
 }
-static void v_sub(int D, const double *a, const double *b, double *o) { for (int i = 0; i < D; i++) o[i] = a[i] - b[i]; }
-static void v_add(int D, const double *a, const double *b, double *o) { for (int i = 0; i < D; i++) o[i] = a[i] + b[i]; }
-static void v_scale(int D, const double *a, double k, double *o) { for (int i = 0; i < D; i++) o[i] = a[i] * k; }
+static void v_sub(int D, const double *a, const double *b, double *o) { FL(D); for (int i = 0; i < D; i++) o[i] = a[i] - b[i]; }
+static void v_add(int D, const double *a, const double *b, double *o) { FL(D); for (int i = 0; i < D; i++) o[i] = a[i] + b[i]; }
+static void v_scale(int D, const double *a, double k, double *o) { FL(D); for (int i = 0; i < D; i++) o[i] = a[i] * k; }
 static void v_neg(int D, const double *a, double *o) { for (int i = 0; i < D; i++) o[i] = -a[i]; }
 static void v_copy(int D, const double *a, double *o) { for (int i = 0; i < D; i++) o[i] = a[i]; }
 static void v_cross3(const double *a, const double *b, double *o) {
+    FL(9);
     double x = a[1] * b[2] - a[2] * b[1];
     double y = a[2] * b[0] - a[0] * b[2];
     double z = a[0] * b[1] - a[1] * b[0];
@@ -157,6 +202,7 @@ static void v_cross3(const double *a, const double *b, double *o) {
 
 /* util.rs:712-722 */
 static double angle_between(int D, const double *a, const double *b) {
+    FL(1); FLD(1);
     double result = eo_acos(v_dot(D, a, b) / (v_norm(D, a) * v_norm(D, b)));
     return eo_isnan(result) ? 0.0 : result;
 }
@@ -309,10 +355,12 @@ static int shape_inside(int D, const obj *sh, const double *p) {
     case SH_VOID: return 1;                                                   /* shape.rs:616-618 */
     case SH_SPHERE: {                                                         /* shape.rs:735-737 */
         double d[MAXD]; v_sub(D, sh->a, p, d);
+        FL(1);
         return v_nsq(D, d) <= sh->r * sh->r;
     }
     case SH_PLANE: return 0;                                                  /* shape.rs:814-816 */
     case SH_HALFSPACE: {                                                      /* shape.rs:874-880 */
+        FL(1);
         double result = v_dot(D, sh->a, p) + sh->r;
         return sh->signum == rust_signum(result);
     }
@@ -320,6 +368,7 @@ static int shape_inside(int D, const obj *sh, const double *p) {
         double q[MAXD], v[MAXD];
         cyl_closest_point_on_axis(D, sh, p, q);
         v_sub(D, p, q, v);
+        FL(1);
         return v_nsq(D, v) <= sh->r * sh->r;
     }
     default: {                                                                /* shape.rs:589-600 */
@@ -522,8 +571,10 @@ static void make_hit(int D, const double *loc, const double *dir, double tt, hit
 
 /* quadratic shared by sphere (shape.rs:667-693) and cylinder (shape.rs:962-988) */
 static int quad_roots(double a, double b, double c, double *t_first, double *t_second, int *has_second) {
+    FL(4);
     double d = b * b - 4.0 * a * c;
     if (d < 0.0) return 0;
+    FL(4); FLD(2);
     double d_sqrt = sqrt(d);
     double t1 = (-b - d_sqrt) / (2.0 * a);
     double t2 = (-b + d_sqrt) / (2.0 * a);
@@ -547,6 +598,7 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
     case SH_SPHERE: {                                                     /* shape.rs:652-731 */
         double rel[MAXD]; v_sub(D, loc, sh->a, rel);
         double a = v_nsq(D, dir);
+        FL(3);
         double b = 2.0 * v_dot(D, dir, rel);
         double c = v_nsq(D, rel) - sh->r * sh->r;
         double t1, t2; int has2;
@@ -561,12 +613,13 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
         break;
     }
     case SH_PLANE: case SH_HALFSPACE: {                                   /* shape.rs:779-809, 843-870 */
+        FL(1); FLD(1);
         double tt = -(v_dot(D, sh->a, loc) + sh->r) / v_dot(D, sh->a, dir);
         if (tt < 0.0) break;
         hit_t *h = &p->imm[p->n_imm++];
         make_hit(D, loc, dir, tt, h);
         v_copy(D, sh->a, h->normal);
-        if (sh->sub == SH_HALFSPACE) { double k = -sh->signum; for (int i = 0; i < D; i++) h->normal[i] *= k; }
+        if (sh->sub == SH_HALFSPACE) { double k = -sh->signum; FL(D); for (int i = 0; i < D; i++) h->normal[i] *= k; }
         break;
     }
     case SH_CYLINDER: {                                                   /* shape.rs:935-1027 */
@@ -575,6 +628,7 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
         v_sub(D, loc, sh->a, delta);
         v_scale(D, sh->b, v_dot(D, delta, sh->b), tmp); v_sub(D, delta, tmp, c_vec);
         double a = v_nsq(D, a_vec);
+        FL(4);
         double b = (1.0 + 1.0) * v_dot(D, a_vec, c_vec);
         double c = v_nsq(D, c_vec) - sh->r * sh->r;
         double t1, t2; int has2;
@@ -706,7 +760,9 @@ static double pow_int(double x, double y) {
     if (!(y == floor(y)) || fabs(y) > 64.0) return NAN;
     int n = (int)fabs(y);
     double r = 1.0;
+    FL(n);
     for (int i = 0; i < n; i++) r = r * x;
+    if (y < 0.0) FLD(1);
     return (y < 0.0) ? 1.0 / r : r;
 }
 
@@ -716,10 +772,10 @@ static double eval_expr(const expr_node *e, const char *legend, const double *ct
     case EX_VAR:
         if (strlen(e->var) == 1) for (int i = 0; i < D && legend[i]; i++) if (legend[i] == e->var[0]) return ctx[i];
         *err = 1; return NAN;
-    case EX_ADD: return eval_expr(e->l, legend, ctx, D, err) + eval_expr(e->r, legend, ctx, D, err);
-    case EX_SUB: return eval_expr(e->l, legend, ctx, D, err) - eval_expr(e->r, legend, ctx, D, err);
-    case EX_MUL: return eval_expr(e->l, legend, ctx, D, err) * eval_expr(e->r, legend, ctx, D, err);
-    case EX_DIV: return eval_expr(e->l, legend, ctx, D, err) / eval_expr(e->r, legend, ctx, D, err);
+    case EX_ADD: FL(1); return eval_expr(e->l, legend, ctx, D, err) + eval_expr(e->r, legend, ctx, D, err);
+    case EX_SUB: FL(1); return eval_expr(e->l, legend, ctx, D, err) - eval_expr(e->r, legend, ctx, D, err);
+    case EX_MUL: FL(1); return eval_expr(e->l, legend, ctx, D, err) * eval_expr(e->r, legend, ctx, D, err);
+    case EX_DIV: FLD(1); return eval_expr(e->l, legend, ctx, D, err) / eval_expr(e->r, legend, ctx, D, err);
     case EX_REM: return fmod(eval_expr(e->l, legend, ctx, D, err), eval_expr(e->r, legend, ctx, D, err));
     case EX_POW: return pow_int(eval_expr(e->l, legend, ctx, D, err), eval_expr(e->r, legend, ctx, D, err));
     case EX_NEG: return -eval_expr(e->l, legend, ctx, D, err);
@@ -817,6 +873,7 @@ static int is_normal(double x) { return isnormal(x); }
 typedef struct { double r, g, b, a; } pre_t;   /* PreAlpha<Rgb<F>, F> */
 
 static pre_t into_premultiplied(rgba_t c) {
+    FL(3);
     double alpha = clamp01(c.a);
     pre_t p = { c.r * alpha, c.g * alpha, c.b * alpha, alpha };
     return p;
@@ -824,7 +881,7 @@ static pre_t into_premultiplied(rgba_t c) {
 static rgba_t from_premultiplied(pre_t p) {
     double alpha = clamp01(p.a);
     rgba_t c;
-    if (is_normal(alpha)) { c.r = p.r / alpha; c.g = p.g / alpha; c.b = p.b / alpha; }
+    if (is_normal(alpha)) { FLD(3); c.r = p.r / alpha; c.g = p.g / alpha; c.b = p.b / alpha; }
     else { c.r = 0.0; c.g = 0.0; c.b = 0.0; }
     c.a = alpha;
     return c;
@@ -832,6 +889,12 @@ static rgba_t from_premultiplied(pre_t p) {
 
 static double blend_chan(int fn, double a, double b, double sa, double da) {
     const double one = 1.0, two = 2.0;
+#ifdef EO_COUNT_FLOPS
+    {   /* adds / multiplies of the formula taken (the divisions of dodge / burn / soft_light are counted with them: 1-2 each) */
+        static const unsigned char BLEND_FL[BL_COUNT] = { 3, 1, 2, 5, 7, 1, 9, 3, 10, 10, 10, 13, 13, 10, 16, 6, 4, 0 };
+        FL(BLEND_FL[fn < BL_COUNT ? fn : 0]);
+    }
+#endif
     switch (fn) {
     case BL_OVER: return a + b * (one - sa);
     case BL_INSIDE: return a * da;
@@ -871,6 +934,7 @@ static double blend_chan(int fn, double a, double b, double sa, double da) {
     }
 }
 static double blend_alpha(int fn, double sa, double da) {
+    FL(3);
     switch (fn) {
     case BL_INSIDE: return clamp01(sa * da);
     case BL_OUTSIDE: return clamp01(sa * (1.0 - da));
@@ -896,6 +960,7 @@ static rgba_t combine_palette_color(rgba_t a, rgba_t b, double a_ratio) {
     if (a_ratio <= 0.0) return b;
     if (a_ratio >= 1.0) return a;
     rgba_t o;
+    FL(16);
     o.r = a.r * a_ratio + b.r * (1.0 - a_ratio);
     o.g = a.g * a_ratio + b.g * (1.0 - a_ratio);
     o.b = a.b * a_ratio + b.b * (1.0 - a_ratio);
@@ -906,12 +971,13 @@ static rgba_t combine_palette_color(rgba_t a, rgba_t b, double a_ratio) {
 /* RgbPixel for [u8;N]: clamp(c,0,1)*255 cast with truncation (UNVERIFIED).  A NaN would panic
  * in NumCast; the oracle writes 0 and counts it. */
 static uint8_t to_u8(tctx *t, double c) {
+    FL(1);
     double v = clamp01(c) * 255.0;
     if (eo_isnan(v)) { if (t) t->stats.nan_pixels++; return 0; }
     return (uint8_t)v;
 }
 static void to_pixel4(tctx *t, rgba_t c, uint8_t *px) { px[0] = to_u8(t, c.r); px[1] = to_u8(t, c.g); px[2] = to_u8(t, c.b); px[3] = to_u8(t, c.a); }
-static rgba_t new_u8(const uint8_t *px) { rgba_t c = { (double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0, (double)px[3] / 255.0 }; return c; }
+static rgba_t new_u8(const uint8_t *px) { FLD(4); rgba_t c = { (double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0, (double)px[3] / 255.0 }; return c; }
 
 /* Hsv -> Rgb, RgbHue::to_positive_degrees (palette 0.2.1, UNVERIFIED) */
 static void hsv_to_rgb(double hue, double saturation, double value, double *r, double *g, double *b) {
@@ -920,6 +986,7 @@ static void hsv_to_rgb(double hue, double saturation, double value, double *r, d
         while (deg >= 360.0) deg = deg - 360.0;
         while (deg < 0.0) deg = deg + 360.0;
     }
+    FL(7); FLD(1);
     double c = value * saturation;
     double h = deg / 60.0;
     double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
@@ -955,9 +1022,10 @@ static void perlin_build_perm(uint32_t seed, uint8_t *perm512) {
     }
     for (int i = 0; i < 512; i++) perm512[i] = p[i & 255];
 }
-static double pfade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
-static double plerp(double t, double a, double b) { return a + t * (b - a); }
+static double pfade(double t) { FL(7); return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+static double plerp(double t, double a, double b) { FL(3); return a + t * (b - a); }
 static double pgrad4(int hash, double x, double y, double z, double w) {
+    FL(2);
     int h = hash & 31;
     double a = (h < 24) ? x : y;
     double b = (h < 16) ? y : z;
@@ -968,6 +1036,7 @@ static int pcell(double f) { double m = fmod(f, 256.0); return (m == m) ? (((int
 static double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
     double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
     int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
+    FL(4 + 16 * 4 + 1);      /* fractions, the 16 corners' offsets, the final scale */
     double xf = x - fx, yf = y - fy, zf = z - fz, wf = w - fw;
     double u = pfade(xf), v = pfade(yf), s = pfade(zf), q = pfade(wf);
     double n[16];
@@ -1081,6 +1150,7 @@ static void uv_eval(const obj *uv, const double *point, double *u, double *v) {
     double p[3], pn[3];                                                     /* d3/entity/surface.rs:60-68 */
     v_sub(3, point, uv->a, p);
     v_normalize(3, p, pn);
+    FL(3); FLD(2);
     *u = 0.5 + eo_atan2(pn[1], pn[0]) / (2.0 * EO_PI_C);
     *v = 0.5 - eo_asin(pn[2]) / EO_PI_C;
 }
@@ -1095,6 +1165,7 @@ static int cast_u32(tctx *t, double x, uint32_t *out) {
 static rgba_t texture_eval(tctx *t, const obj *tx, double pu, double pv) {
     uint32_t W = tx->w, H = tx->h;
     if (tx->sub == EO_TEX_NEAREST) {                                        /* surface.rs:434-451 */
+        FL(2); FLD(4);
         double x = floor(pu * (double)W), y = floor(pv * (double)H);
         uint32_t xi, yi;
         cast_u32(t, x, &xi); cast_u32(t, y, &yi);
@@ -1104,6 +1175,7 @@ static rgba_t texture_eval(tctx *t, const obj *tx, double pu, double pv) {
         rgba_t c = { (double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0, (double)px[3] / 255.0 };
         return c;
     }
+    FL(6 + 4 + 2 + 4 * 9); FLD(4);            /* coordinates, offsets, the two weights, 4 channels x 9 */
     double x = pu * (double)W - 0.5, y = pv * (double)H - 0.5;             /* surface.rs:453-489 */
     double ox = x - floor(x), oy = y - floor(y);
     static const double OFF[4][2] = { {0, 0}, {1, 0}, {0, 1}, {1, 1} };
@@ -1151,6 +1223,7 @@ static void general_rotation(int D, const double *self, const double *other, dou
             double oc[MAXD], rj[MAXD];
             for (int r = 0; r < D; r++) { oc[r] = orig[r][i]; rj[r] = res[r][j]; }
             double d = v_dot(D, rj, oc);
+            FL(2 * D);
             for (int r = 0; r < D; r++) orig[r][i] = oc[r] - rj[r] * d;
         }
         double col[MAXD], nc[MAXD];
@@ -1163,6 +1236,7 @@ static void general_rotation(int D, const double *self, const double *other, dou
     double ca = eo_cos(angle), sa = eo_sin(angle);
     rot[0][0] = ca; rot[0][1] = -sa; rot[1][0] = sa; rot[1][1] = ca;
     double tmp[MAXD][MAXD], fin[MAXD][MAXD];
+    FL(2 * (2 * D * D * D) + 2 * D * D);      /* two matrix products and the matrix-vector product */
     for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) {           /* rotation * result^T */
         double acc = 0.0;
         for (int k = 0; k < D; k++) acc = acc + rot[r][k] * res[c][k];
@@ -1190,8 +1264,10 @@ static double reflection_ratio(tctx *t, const obj *p, const trace_ctx *c) {
     double from_theta = angle_between(D, c->intersection.direction, normal);
     double from_index, to_index;
     if (c->exiting) { from_index = p->p0; to_index = p->p1; } else { from_index = p->p1; to_index = p->p0; }
+    FL(1); FLD(1);
     double to_theta = eo_asin((from_index / to_index) * eo_sin(from_theta));
     if (eo_isnan(to_theta)) return 1.0;
+    FL(4 + 4 + 2 + 1); FLD(3);
     double product_1_s = from_index * eo_cos(from_theta);
     double product_2_s = to_index * eo_cos(to_theta);
     double product_1_p = from_index * eo_cos(to_theta);
@@ -1204,6 +1280,7 @@ static double reflection_ratio(tctx *t, const obj *p, const trace_ctx *c) {
 static void reflection_direction(tctx *t, const trace_ctx *c, double *out) {   /* surface.rs:246-256 */
     int D = t->D;
     double d = v_dot(D, c->intersection.direction, c->normal_closer);
+    FL(3 * D);
     for (int i = 0; i < D; i++) out[i] = c->normal_closer[i] * -2.0 * d + c->intersection.direction[i];
 }
 
@@ -1214,6 +1291,8 @@ static void threshold_direction(tctx *t, const obj *p, const trace_ctx *c, doubl
     double normal[MAXD];                                                    /* surface.rs:268-288 */
     v_neg(D, c->normal_closer, normal);
     double from_theta = angle_between(D, c->intersection.direction, normal);
+    if (!c->exiting) FLD(1);
+    FL(2);
     double modifier = c->exiting ? p->p0 : 1.0 / p->p0;
     double to_theta = eo_asin(modifier * eo_sin(from_theta));
     double angle_delta = to_theta - from_theta;
@@ -1232,6 +1311,7 @@ static rgba_t surface_color(tctx *t, const obj *p, const trace_ctx *c) {
     }
     case COL_ILLUM_GLOBAL: {                                                /* surface.rs:410-422 */
         double original_angle = angle_between(D, c->normal_closer, c->intersection.direction);
+        FL(1); FLD(1);
         double angle = EO_PI_C - original_angle;
         double ratio = angle / EO_FRAC_PI_2_C;
         return combine_palette_color(p->c1, p->c0, ratio);
@@ -1242,12 +1322,14 @@ static rgba_t surface_color(tctx *t, const obj *p, const trace_ctx *c) {
         if (angle_between(D, c->intersection.direction, normal) > EO_FRAC_PI_2_C) v_neg(D, normal, normal);
         v_neg(D, p->dir, nl);
         double angle = angle_between(D, normal, nl);
+        FL(1); FLD(1);
         double ratio = 1.0 - angle / EO_PI_C;
         return combine_palette_color(p->c1, p->c0, ratio);
     }
     case COL_PERLIN: {                                                      /* d3/entity/surface.rs:22-40 */
         double time_millis = (double)t->time_ms / 1000.0;
         const double *l = c->intersection.location;
+        FL(2); FLD(4);
         double value = perlin4(p->perm, l[0] / p->p0, l[1] / p->p0, l[2] / p->p0, time_millis * p->p1);
         rgba_t o;
         hsv_to_rgb(value * 360.0, 1.0, 1.0, &o.r, &o.g, &o.b);
@@ -1316,6 +1398,7 @@ static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c,
         else {
             double tdir[MAXD], new_origin[MAXD];
             threshold_direction(t, surface->o2, c, tdir);
+            FL(3 * D);
             for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + -c->normal_closer[i] * EO_EPS128_A * 128.0;
             const obj *dest = c->exiting ? material_at(t, new_origin) : c->intersection_traceable;
             if (dest) {
@@ -1332,6 +1415,7 @@ static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c,
     if (!(ratio <= 0.0)) {                                                  /* get_reflection_color */
         double rdir[MAXD], new_origin[MAXD];
         reflection_direction(t, c, rdir);
+        FL(3 * D);
         for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + c->normal_closer[i] * EO_EPS128_A * 128.0;
         refl = trace(t, depth_remaining - 1, c->origin_traceable, new_origin, rdir, NULL);
         have_refl = 1;
@@ -1357,6 +1441,7 @@ static rgba_t trace(tctx *t, uint32_t max_depth, const obj *belongs_to, const do
     }
     t->stats.bg_samples++;
     double pt[MAXD];
+    FL(D);
     for (int i = 0; i < D; i++) pt[i] = 0.0 + dir[i];                       /* direction.to_point(), util.rs:616-618 */
     return mapped_get_color(t, t->scene->background, pt);
 }
@@ -1592,6 +1677,7 @@ static void camera_ray(const eo_camera *cam, int sx, int sy, int sw, int sh, dou
     double right[MAXD];
     if (D == 3) { double cr[MAXD]; v_cross3(cam->forward, cam->up, cr); v_normalize(3, cr, right); }
     else v_neg(D, cam->left, right);
+    FL(2 + 1 + 3 + 1 + 6 * D); FLD(2 + 2 + 2);
     double fov_rad = EO_PI_C * (double)cam->fov_deg / 180.0;
     double dist = sqrt(w * w + h * h) / (2.0 * eo_tan(fov_rad / 2.0));
     double p[MAXD];
@@ -1656,12 +1742,34 @@ static void *worker(void *arg) {
             if (j->hit_t) j->hit_t[idx] = hit;
         }
     }
+#ifdef EO_COUNT_FLOPS
+    pthread_mutex_lock(&eo_fl_mu);
+    for (int k = 0; k < 4; k++) { eo_fl_total[k] += eo_fl[k]; eo_fl[k] = 0; }
+    pthread_mutex_unlock(&eo_fl_mu);
+#endif
     pthread_mutex_lock(&j->mu);
     j->stats.rays += t.stats.rays; j->stats.bg_samples += t.stats.bg_samples;
     j->stats.nan_pixels += t.stats.nan_pixels; j->stats.errors += t.stats.errors; j->stats.spins += t.stats.spins;
     pthread_mutex_unlock(&j->mu);
     free(t.arena);
     return NULL;
+}
+
+/* -DEO_COUNT_FLOPS builds: operations counted since the last call (add/sub/mul, div, sqrt, transcendental calls); zeros otherwise */
+void eo_flops_take(unsigned long long out[4]) {
+    pthread_mutex_lock(&eo_fl_mu);
+    for (int k = 0; k < 4; k++) { out[k] = eo_fl_total[k]; eo_fl_total[k] = 0; }
+    pthread_mutex_unlock(&eo_fl_mu);
+}
+int eo_build_flags(void) {
+    int f = 0;
+#ifdef EO_COUNT_FLOPS
+    f |= 1;
+#endif
+#ifdef EO_USE_LIBM
+    f |= 2;
+#endif
+    return f;
 }
 
 int eo_render(const eo_scene *s, const eo_camera *cam, const eo_frame *f, int threads, uint8_t *rgb, double *hit_t, eo_stats *stats) {

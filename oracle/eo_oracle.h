@@ -127,6 +127,11 @@ typedef struct {
 /* 0 = updated, 1 = the reference reaches unimplemented!() (4-D, direction turned), -1 = path step cap */
 int eo_camera_update(const eo_scene *, int kind, eo_camera *, const eo_input *);
 
+/* variant builds (oracle/Makefile): libeo_oracle_flops.so counts the f64 operations of the algorithm,
+ * libeo_oracle_libm.so takes the elementary functions from the platform libm.  eo_build_flags: bit 0 flops, bit 1 libm. */
+void eo_flops_take(unsigned long long out[4]);
+int eo_build_flags(void);
+
 int eo_render(const eo_scene *, const eo_camera *, const eo_frame *, int threads,
               uint8_t *rgb_out /* (row_end-row_begin)*width*3 */,
               double *hit_t /* optional, per pixel: distance of the primary ray's closest hit, -1 if none */,

@@ -48,21 +48,24 @@ class Intersection(C.Structure):
                 ("normal", C.c_double * 4), ("distance", C.c_double)]
 
 
-_lib = None
+_libs = {}
+VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so"}
 
 
-def build(force=False):
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", HERE, "libeo_oracle.so"], stdout=subprocess.DEVNULL)
-    return LIB_PATH
+def build(force=False, variant=""):
+    path = os.path.join(HERE, VARIANTS[variant])
+    if force or not os.path.exists(path):
+        subprocess.check_call(["make", "-C", HERE, VARIANTS[variant]], stdout=subprocess.DEVNULL)
+    return path
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    build()
-    L = C.CDLL(LIB_PATH)
+def lib(variant=""):
+    """The oracle library.  variant "flops": the same restatement with f64 operation counters (eo_flops_take);
+    "libm": elementary functions from the platform libm instead of eo_math.h.  Both are measurement builds."""
+    if variant in _libs:
+        return _libs[variant]
+    L = C.CDLL(build(variant=variant))
+    _libs[variant] = L
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int)
     vp = C.c_void_p
@@ -128,8 +131,9 @@ def lib():
     sig("eo_test_blend", None, C.c_char_p, dp, dp, dp)
     sig("eo_test_math", None, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
     sig("eo_test_perlin", C.c_double, C.c_uint32, dp)
+    sig("eo_flops_take", None, C.POINTER(C.c_uint64 * 4))
+    sig("eo_build_flags", C.c_int)
     sig("eo_test_ray", None, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, dp, dp)
-    _lib = L
     return L
 
 
@@ -142,6 +146,13 @@ def dvec(vals, n=4):
 
 def ivec(vals):
     return (C.c_int * max(1, len(vals)))(*vals)
+
+
+def flops_take(variant="flops"):
+    """Operations the "flops" build counted since the last call: dict add_mul / div / sqrt / transcendental."""
+    out = (C.c_uint64 * 4)()
+    lib(variant).eo_flops_take(C.byref(out))
+    return {"add_mul": int(out[0]), "div": int(out[1]), "sqrt": int(out[2]), "transcendental": int(out[3])}
 
 
 def default_threads():
@@ -202,8 +213,9 @@ def default_texture_loader(search_dirs):
 class OracleScene:
     """Walks a scene JSON (scene.rs Appendix-B format) and builds an eo_scene."""
 
-    def __init__(self, text, texture_loader=None, random_seed=0):
-        self.L = lib()
+    def __init__(self, text, texture_loader=None, random_seed=0, variant=""):
+        self.variant = variant
+        self.L = lib(variant)
         self.random_seed = random_seed
         self.texture_loader = texture_loader or default_texture_loader([os.getcwd()])
         try:
@@ -475,8 +487,8 @@ class OracleScene:
         return rgb, hit, stats
 
 
-def load_scene_file(path, texture_dirs=None, random_seed=0):
+def load_scene_file(path, texture_dirs=None, random_seed=0, variant=""):
     with open(path) as f:
         text = f.read()
     dirs = list(texture_dirs or []) + [os.path.dirname(os.path.dirname(os.path.abspath(path))), os.getcwd()]
-    return OracleScene(text, default_texture_loader(dirs), random_seed)
+    return OracleScene(text, default_texture_loader(dirs), random_seed, variant)

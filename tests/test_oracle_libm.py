@@ -1,0 +1,50 @@
+"""How far does the last bit of the elementary functions move the picture?
+
+The reference calls the platform libm (Rust's f64::acos/asin/sin/cos/tan/atan2); the oracle and the HIP kernels share their
+own fdlibm-style routines (oracle/eo_math.h, csrc/eu_math.h), which differ from glibc by at most 1 ulp -- in 3-18 % of
+the arguments.  `libeo_oracle_libm.so` is the same restatement with glibc's functions.  This test renders the BASELINE
+configurations with both and reports the differing RGB bytes and ray counts (numbers at full size: DESIGN.md section 2).
+
+What it pins: a 1-ulp difference never moves a byte by more than 1, and moves a bounded share of them; the mechanism is the
+`alpha == 255` test of get_intersection_color (surface.rs:73): an opaque blend's alpha is (sa + 1) - sa, i.e. 1 or 1 - 2^-53
+depending on sa's last bit, 255 or 254 after to_pixel's truncation.
+"""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = [("3d_fresnel.json", 256, 256, 4), ("3d_room.json", 320, 180, 8), ("3d_hallways.json", 320, 180, 12),
+           ("4d_frame.json", 320, 180, 8)]
+
+
+@pytest.mark.parametrize("scene,w,h,depth", CONFIGS)
+def test_libm_last_bit_sensitivity(scene, w, h, depth, capsys):
+    from oracle.scene_loader import lib, load_scene_file
+    assert lib("libm").eo_build_flags() & 2 and not lib().eo_build_flags() & 2
+    path = os.path.join(ROOT, "scenes", scene)
+    a, _, sa = load_scene_file(path).render(w, h, max_depth=depth)
+    b, _, sb = load_scene_file(path, variant="libm").render(w, h, max_depth=depth)
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    with capsys.disabled():
+        print("\n  %-18s %dx%d d%-2d: %6d of %d bytes differ (%.2f %%), max |diff| %d, rays %d vs %d" % (
+            scene, w, h, depth, int((d != 0).sum()), d.size, 100.0 * (d != 0).mean(), int(d.max()), sa["rays"], sb["rays"]))
+    assert int(d.max()) <= 1
+    assert (d != 0).mean() < 0.08
+    assert abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
+
+
+def test_flops_build_is_the_same_algorithm():
+    """The operation-counting build (bench.py's roofline.flops) renders the same bytes and counts something."""
+    from oracle.scene_loader import flops_take, lib, load_scene_file
+    assert lib("flops").eo_build_flags() & 1
+    path = os.path.join(ROOT, "scenes", "3d_room.json")
+    a, _, sa = load_scene_file(path).render(160, 90, max_depth=6)
+    flops_take()
+    b, _, sb = load_scene_file(path, variant="flops").render(160, 90, max_depth=6)
+    fl = flops_take()
+    assert np.array_equal(a, b) and sa == sb
+    per_ray = sum(fl.values()) / sa["rays"]
+    assert 200 < per_ray < 5000 and fl["div"] > 0 and fl["sqrt"] > 0 and fl["transcendental"] > 0
+    assert flops_take() == {"add_mul": 0, "div": 0, "sqrt": 0, "transcendental": 0}

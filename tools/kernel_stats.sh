@@ -4,7 +4,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 env "$@" true
 for kv in "$@"; do export "$kv"; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1 || exit 1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/prof_%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True)

@@ -1,6 +1,6 @@
 """Turn the rocprofv3 --pmc passes of tools/pmc_passes.sh (gpurun_out/pmc) into profiles/<tag>_pmc.json and refresh
 profiles/traffic.json (HBM bytes and wave-level VALU instructions of one frame pipeline).
-Usage: python tools/pmc_to_profile.py r01_k "stage description" """
+Usage: python tools/pmc_to_profile.py r02_room "stage description" ["3d_room.json 1920x1080 depth 8" [pmc_dir [round]]] """
 import collections
 import csv
 import glob
@@ -10,9 +10,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stage = sys.argv[1], sys.argv[2]
-workload = "3d_room.json 1920x1080 depth 8"
+workload = sys.argv[3] if len(sys.argv) > 3 else "3d_room.json 1920x1080 depth 8"
+pmc_dir = sys.argv[4] if len(sys.argv) > 4 else "pmc"
+round_no = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(ROOT, "gpurun_out/pmc/*/*/*counter_collection.csv")):
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", pmc_dir, "*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "eu_" in name:
@@ -23,7 +25,7 @@ for name, cs in vals.items():
     per_kernel[name] = {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
 for name in vals:
     n = per_kernel[name]["SQ_WAVES"]["launches"] if "SQ_WAVES" in per_kernel[name] else 0
-    if name.startswith("eu_wf_gen"):
+    if name.startswith("eu_wf_gen") or name.startswith("eu_ts_kernel"):
         frames = n
 for name in vals:
     n = max(v["launches"] for v in per_kernel[name].values())
@@ -48,7 +50,7 @@ wide = [n for n in vals if n.startswith("eu_pack_rgb") and "FETCH_SIZE" in per_k
 fetch_corrected = fetch + sum(launches[n] * per_kernel[n]["FETCH_SIZE"]["avg_per_launch"] * 1024 for n in wide)
 valu = sum(launches[n] * derived[n].get("SQ_INSTS_VALU_per_launch", 0.0) for n in vals)
 lanes = sum(launches[n] * derived[n].get("SQ_INSTS_VALU_per_launch", 0.0) * derived[n].get("VALU_lane_utilisation_pct", 0.0) / 100 for n in vals)
-out = {"round": 1, "stage": stage + "; counters collected with EU_WF_STREAMS=1 so that per-dispatch counters do not mix between concurrent kernels",
+out = {"round": round_no, "stage": stage + "; counters collected with EU_WF_STREAMS=1 so that per-dispatch counters do not mix between concurrent kernels",
        "workload": workload, "launches_per_frame_single_stream": launches, "derived": derived, "per_kernel": per_kernel,
        "frame_hbm_bytes": {"FETCH_SIZE_sum": fetch, "WRITE_SIZE_sum": write, "hbm_bytes_per_frame_raw": fetch + write,
                            "hbm_bytes_per_frame_fetch_doubled": 2 * fetch + write, "hbm_bytes_per_frame_calibrated": fetch_corrected + write,
