@@ -113,6 +113,7 @@ struct eu_renderer {
     static constexpr int WF_MAX_STREAMS = 4;
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
+    uint32_t wf_depth = 0;                   /* deepest max_depth the node slots are sized for */
     hipStream_t wf_stream[WF_MAX_STREAMS] = {};
     hipEvent_t wf_fork = nullptr, wf_join[WF_MAX_STREAMS] = {};
     int wf_n_streams = 2;                    /* EU_WF_STREAMS (1 = everything on the caller's stream) */
@@ -284,8 +285,10 @@ static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCa
 
 
 /* ------------------------------------------------------------------ wavefront pipeline (trace_wavefront.h) */
-static int wf_ensure(eu_renderer *r, size_t pixels) {
-    if (pixels <= r->wf_pixels) return EU_OK;
+static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth) {
+    if (pixels <= r->wf_pixels && max_depth <= r->wf_depth) return EU_OK;
+    if (pixels < r->wf_pixels) pixels = r->wf_pixels;
+    if (max_depth > r->wf_depth) r->wf_depth = max_depth;
     for (void *p : r->wf_allocs) (void)hipFree(p);
     r->wf_allocs.clear();
     r->wf_pixels = 0;
@@ -300,7 +303,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     if (seg_cap < 2048) seg_cap = 2048;        /* small frames: absorb uneven segments */
     seg_cap = (seg_cap + 255) & ~(size_t)255;
     const size_t ray_cap = seg_cap * n_seg;
-    const size_t node_cap = pixels + ray_cap * (EU_MAX_DEPTH + 1);
+    const size_t node_cap = ray_cap * (size_t)(r->wf_depth ? r->wf_depth : 1u);      /* one slot per ray of every generation the deepest frame so far has */
     if (ray_cap > 0x7ffffff0ull || node_cap > 0xfffffff0ull) { r->err = "frame too large for 32-bit queue indices; render it in row tiles"; return EU_ERR_CAPACITY; }
     auto alloc = [&](void **p, size_t bytes) -> int {
         HIP_TRY(hipMalloc(p, bytes));
@@ -318,11 +321,8 @@ static int wf_ensure(eu_renderer *r, size_t pixels) {
     if ((rc = alloc((void **)&B.hit_ent, ray_cap * 4))) return rc;
     /* node ids are static: pixel roots, then generation g's queue slot q at pixels + g*ray_cap + q
      * (only the slots that hold rays are ever touched) */
-    if ((rc = alloc((void **)&B.node_child, node_cap * 8 * sizeof(double)))) return rc;
-    if ((rc = alloc((void **)&B.node_ratio, node_cap * 8))) return rc;
-    if ((rc = alloc((void **)&B.node_px, node_cap * 4))) return rc;
-    if ((rc = alloc((void **)&B.node_meta, node_cap * 4))) return rc;
-    if ((rc = alloc((void **)&B.node_parent, node_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.nodes, node_cap * sizeof(EuTsNode)))) return rc;
+    if ((rc = alloc((void **)&B.node_kind, node_cap))) return rc;
     if ((rc = alloc((void **)&B.seg_count, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4))) return rc;
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
@@ -364,7 +364,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         }
     }
     const size_t band_pixels = (size_t)band_rows * df_in.width;
-    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels);
+    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, dc.max_depth);
     if (rc != EU_OK) return rc;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     if (r->dbg_hs_cap) hs_cap = r->dbg_hs_cap;      /* diagnostics only */
@@ -405,14 +405,11 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
             if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words | dbg_skip, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
             else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
             else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
-            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters);
-            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters);
+            if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters, rgba, point);
+            else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters, rgba, point);
         }
         for (uint32_t g = dc.max_depth; g-- > 0;)
-            hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters);
-        unsigned gf = (unsigned)((B.npix + EU_WF_BLOCK - 1) / EU_WF_BLOCK);
-        if (gf > (unsigned)r->num_cus * 16u) gf = (unsigned)r->num_cus * 16u;
-        hipLaunchKernelGGL(eu_wf_final_kernel, dim3(gf ? gf : 1), dim3(EU_WF_BLOCK), 0, stream, B, df.root_base, r->d_counters, rgba, point);
+            hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters, rgba, point);
         if (df.single_pixel) break;
     }
     if (two_streams) {      /* join */

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "trace_device.h"
+#include "trace_nodes.h"
 
 #define EU_TS_BLOCK 256
 #ifndef EU_TS_CH
@@ -58,19 +59,7 @@ static_assert(EU_TS_CH <= 2048 && EU_TS_CH % EU_TS_BLOCK == 0, "rank field: 11 b
 #define EU_TS_WAVES 3           /* waves per SIMD the kernel is compiled for (168 VGPRs) */
 #endif
 
-enum { TS_NONE = 0, TS_OVER = 2, TS_COMBINE_TRANS = 3, TS_COMBINE_INTER = 4 };
-/* how a colour is handed to its parent: (slot | mode << 1), carried in bits 16..18 of a ray's aux word */
-enum { TS_MODE_F64 = 0, TS_MODE_U8 = 1, TS_MODE_INTER = 2, TS_MODE_ROOT = 3 };
 enum { TS_WORK_DONE = 0, TS_WORK_GENERATE = 1, TS_WORK_PROCESS = 2, TS_WORK_ABORT = 3 };
-
-struct EuTsNode {               /* 64 bytes */
-    double c1[4];               /* slot 1: the reflection's colour (COMBINE_TRANS) | the surface colour, replaced by the combined result when the reflection arrives (COMBINE_INTER) */
-    double ratio;
-    uint32_t c0px;              /* slot 0: the transmitted colour, quantised by whoever delivers it */
-    uint32_t spx;               /* the surface colour, quantised */
-    uint32_t parent;            /* node id, or the pixel's index in the frame buffer */
-    uint32_t meta;              /* kind | (slot | mode << 1) of the parent << 8 */
-};
 
 struct EuTsPool {
     double *ray_od;             /* [n_wg * NCH][2 D][CH] origin then direction, component-major inside a chunk */
@@ -164,37 +153,6 @@ EU_DEV void ts_close_nodes(TsState &st, uint32_t gen, const EuTsPool &P) {
         st.node_spare = EU_TS_NONE;
     } else st.node_fill[gen] = total;
 }
-
-template <int D> EU_DEV Rgba ts_background(const EuScene &S, const double *d, LaneCounters &cnt) {
-    /* background().get_color(&direction.to_point()) (universe/mod.rs:183) */
-    cnt.bg++;
-    double pt[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) pt[i] = 0.0 + d[i];
-    return mapped_get_color(S, S.background, pt, cnt);
-}
-
-/* hand a finished colour to whoever waits for it */
-EU_DEV void ts_deliver(const EuTsPool &P, uint32_t parent, uint32_t slot_mode, const Rgba &c, LaneCounters &cnt,
-                       uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
-    const uint32_t mode = slot_mode >> 1;
-    if (mode == TS_MODE_ROOT) {             /* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-        const Rgba white = {1.0, 1.0, 1.0, 1.0};
-        const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(c), into_premultiplied(white)));
-        rgba[parent] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
-        if (point_rgb) { point_rgb[0] = out.r; point_rgb[1] = out.g; point_rgb[2] = out.b; }
-        return;
-    }
-    EuTsNode *N = P.nodes + parent;
-    if (mode == TS_MODE_U8) { N->c0px = to_pixel4(c, cnt); return; }       /* transition_palette = Rgba::new_u8(transition.to_pixel()), surface.rs:104-112 */
-    Rgba v = c;
-    if (mode == TS_MODE_INTER) {            /* combine_palette_color(reflection, intersection, ratio), surface.rs:159-161 */
-        const Rgba inter = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
-        v = combine_palette_color(c, inter, N->ratio);
-    }
-    N->c1[0] = v.r; N->c1[1] = v.g; N->c1[2] = v.b; N->c1[3] = v.a;
-}
-
 
 /* thread 0: put the finished step's output away, then decide what the workgroup does next */
 EU_DEV void ts_schedule(TsState &st, uint32_t max_depth, uint32_t n_work_tiles, EuDevCounters *counters, const EuTsPool &P) {
@@ -336,7 +294,7 @@ template <int D> EU_DEV void ts_generate(TsState &st, LaneCounters &cnt, int cam
         SG.init(q->scene_g);
         material_apply<D>(SG, SG.entity((uint32_t)cam_ent).material, d, false);
         if (max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
-            ts_deliver(P, out_idx, TS_MODE_ROOT << 1, ts_background<D>(SG, d, cnt), cnt, rgba, point_rgb);
+            ts_deliver(P.nodes, out_idx, TS_MODE_ROOT << 1, ts_background<D>(SG, d, cnt), cnt, rgba, point_rgb);
             break;
         }
         ent_u = (uint32_t)cam_ent;
@@ -523,7 +481,7 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
                     }
                 } else {
                     if (!have_inter) cnt.errors++;            /* the reference panics here (surface.rs:154) */
-                    ts_deliver(P, parent, sm, inter, cnt, rgba, point_rgb);
+                    ts_deliver(P.nodes, parent, sm, inter, cnt, rgba, point_rgb);
                 }
             }
         }
@@ -547,7 +505,7 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
                 double dd[D];
 #pragma unroll
                 for (int qq = 0; qq < D; qq++) dd[qq] = k ? c_d[1][qq] : c_d[0][qq];
-                ts_deliver(P, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
+                ts_deliver(P.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
             }
         }
         uint32_t pos1;
@@ -575,7 +533,7 @@ EU_DEV void ts_resolve(TsState &st, LaneCounters &cnt) {
                     const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
                     res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
                 }
-                ts_deliver(P, N->parent, (meta >> 8) & 7u, res, cnt, rgba, point_rgb);
+                ts_deliver(P.nodes, N->parent, (meta >> 8) & 7u, res, cnt, rgba, point_rgb);
             }
             chunk = P.nchunk_prev[chunk]; count = EU_TS_NCN;
         }

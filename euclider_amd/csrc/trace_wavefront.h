@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "trace_device.h"
+#include "trace_nodes.h"
 
 #define EU_WF_BLOCK 256
 #ifndef EU_WF_WIN
@@ -53,7 +54,6 @@
 #define WF_SUB(k) do { } while (0)
 #endif
 
-enum { WF_NONE = 0, WF_ROOT = 1, WF_OVER = 2, WF_COMBINE_TRANS = 3, WF_COMBINE_INTER = 4 };
 
 struct EuWfBuffers {
     double *ray_od[2];          /* [2*D][ray_cap] origin then direction, component-major; ping-pong by generation */
@@ -62,15 +62,12 @@ struct EuWfBuffers {
     double *hit_t;              /* per ray of the current generation */
     uint32_t *hit_code;
     uint32_t *hit_ent;          /* 0xffffffff: nothing hit */
-    /* tree nodes: id < npix are the per-pixel roots, then one id per traced ray in queue order */
-    double *node_child;         /* [node_cap][2][4] colours delivered by the children */
-    double *node_ratio;
-    uint32_t *node_px;
-    uint32_t *node_meta;        /* kind | slot-in-parent << 8 */
-    uint32_t *node_parent;
+    /* tree nodes (trace_nodes.h): one id per traced ray in queue order, only the slots of rays that need one are touched */
+    EuTsNode *nodes;            /* [node_cap] */
+    uint8_t *node_kind;         /* [node_cap] TS_NONE / TS_OVER / ...: what resolve has to do for the ray in this slot */
     uint32_t *seg_count;        /* [EU_MAX_DEPTH + 1][n_seg] rays in each segment of each generation's queue */
     uint32_t ray_cap, node_cap, npix, pad;
-    uint32_t n_seg, seg_cap;    /* ray_cap = n_seg * seg_cap; node id of queue slot q of generation g = npix + g * ray_cap + q */
+    uint32_t n_seg, seg_cap;    /* ray_cap = n_seg * seg_cap; node id of queue slot q of generation g = g * ray_cap + q */
 };
 
 EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) {
@@ -142,20 +139,6 @@ EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_
     return lo * seg_cap + (v - pref[lo]);
 }
 
-EU_DEV void wf_deliver(const EuWfBuffers &B, uint32_t parent, uint32_t slot, const Rgba &c) {
-    double *p = B.node_child + ((size_t)parent * 2 + slot) * 4;
-    p[0] = c.r; p[1] = c.g; p[2] = c.b; p[3] = c.a;
-}
-
-template <int D> EU_DEV Rgba wf_background(const EuScene &S, const double *d, LaneCounters &cnt) {
-    /* background().get_color(&direction.to_point()) (universe/mod.rs:183) */
-    cnt.bg++;
-    double pt[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) pt[i] = 0.0 + d[i];
-    return mapped_get_color(S, S.background, pt, cnt);
-}
-
 /* ------------------------------------------------------------------ queue helpers */
 struct WfRay { uint32_t q; };
 
@@ -213,12 +196,10 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                     if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
                         rgba[out_idx] = 0u;
                         if (hit_t) hit_t[out_idx] = -1.0;
-                        B.node_meta[out_idx - fr.root_base] = WF_NONE;
                         break;
                     }
                 } else px_y = fr.row_begin + ry;
             }
-            B.node_meta[out_idx - fr.root_base] = WF_NONE;
             if (hit_t) hit_t[out_idx] = -1.0;
             /* Environment::render's cross-hair (universe/mod.rs:321-333) */
             const uint32_t hw = fr.width / 2, hh = fr.height / 2;
@@ -249,9 +230,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                 break;
             }
             material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
-            B.node_meta[out_idx - fr.root_base] = WF_ROOT;
             if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
-                wf_deliver(B, out_idx - fr.root_base, 0, wf_background<D>(S, d, cnt));
+                ts_deliver(B.nodes, out_idx, TS_MODE_ROOT << 1, ts_background<D>(S, d, cnt), cnt, rgba, point_rgb);
                 break;
             }
             ent_u = (uint32_t)ent;
@@ -261,7 +241,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
         const uint32_t pos = wf_append_local(&seg_fill, have_ray ? 1u : 0u, second);
         if (have_ray) {
             if (pos >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
-            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx - fr.root_base, ent_u);
+            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx, ent_u | ((uint32_t)(TS_MODE_ROOT << 1) << 16));      /* the colour goes straight to the pixel */
         }
     }
     __syncthreads();
@@ -367,7 +347,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;
             B.hit_ent[i] = best_ent;
-            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i] + root_base] = have ? best_t : -1.0;
+            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -1.0;      /* a primary ray's parent is its pixel */
             IS_STAMP(15);
         }
     }
@@ -384,7 +364,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
 template <int D, bool SCENE_LDS>
 __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth /* diagnostic builds: | EU_DEBUG_SKIP_SHADE << 16 */, double time_s,
-                                                                  EuWfBuffers B, EuDevCounters *counters) {
+                                                                  EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
 #ifdef EU_DEBUG_SKIP      /* EU_DEBUG_SKIP_SHADE bits (in max_depth's high half): 1 constant background, 2 constant opaque surface colour, 4 ratio 0 */
     const uint32_t dbg_shade = max_depth >> 16;
     max_depth &= 0xffffu;
@@ -413,7 +393,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
     const uint32_t out_base = blockIdx.x * B.seg_cap;
-    const uint32_t node_base = B.npix + gen * B.ray_cap;       /* node id of queue slot q: node_base + q */
+    const uint32_t node_base = gen * B.ray_cap;       /* node id of queue slot q: node_base + q */
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
@@ -458,26 +438,27 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             const uint32_t i = live ? sorted[sidx] : 0u;
             WF_STAMP(0);
             const uint32_t nid = node_base + i;
-            /* children of this ray: 0 = transmission, 1 = reflection */
+            /* children of this ray: 0 = transmission, 1 = reflection; c_sm = slot | delivery mode << 1 (trace_nodes.h) */
             uint32_t n_child = 0;
             double c_o[2][D], c_d[2][D];
-            uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_slot[2] = {0, 0};
+            uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_sm[2] = {0, 0};
+            bool bg_miss = false;
             if (live) {
                 WF_STAMP(1);
                 const uint32_t parent = B.ray_parent[in][i];
                 const uint32_t aux = B.ray_aux[in][i];
-                const uint32_t ent = aux & 0xffffu, slot = (aux >> 16) & 1u;
+                const uint32_t ent = aux & 0xffffu, sm = (aux >> 16) & 7u;
                 double o[D], d[D];
 #pragma unroll
                 for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
                 const uint32_t hit_ent = B.hit_ent[i];
-                uint32_t node_kind = WF_NONE;
+                uint32_t node_kind = TS_NONE;
                 if (hit_ent == 0xffffffffu) {
                     /* nothing hit: the background colour goes to the parent; handled as a depth-0 "child" below */
 #pragma unroll
                     for (int k = 0; k < D; k++) { c_o[0][k] = o[k]; c_d[0][k] = d[k]; }
-                    c_parent[0] = parent; c_slot[0] = slot | 2u;       /* bit 1: background only */
-                    n_child = 1;
+                    c_parent[0] = parent; c_sm[0] = sm;
+                    n_child = 1; bg_miss = true;
                 } else {
                     const double best_t = B.hit_t[i];
                     const uint32_t best_code = B.hit_code[i];
@@ -536,38 +517,37 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                             if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
                         }
                     }
-                    if (need_trans) {
-                        node_kind = need_refl ? WF_COMBINE_TRANS : WF_OVER;
-                        B.node_px[nid] = spx;
-                        if (need_refl) B.node_ratio[nid] = ratio;
-                        B.node_parent[nid] = parent;
-                        c_ent[0] = (uint32_t)dest; c_parent[0] = nid; c_slot[0] = 0u;
+                    EuTsNode *N = B.nodes + nid;
+                    if (need_trans) {      /* the transmitted colour arrives quantised (slot 0), the reflection as it is (slot 1) */
+                        node_kind = need_refl ? TS_COMBINE_TRANS : TS_OVER;
+                        N->spx = spx; N->parent = parent; N->meta = node_kind | (sm << 8);
+                        if (need_refl) N->ratio = ratio;
+                        c_ent[0] = (uint32_t)dest; c_parent[0] = nid; c_sm[0] = 0u | (TS_MODE_U8 << 1);
                         n_child = 1;
-                        if (need_refl) { c_ent[1] = ent; c_parent[1] = nid; c_slot[1] = 1u; n_child = 2; }
+                        if (need_refl) { c_ent[1] = ent; c_parent[1] = nid; c_sm[1] = 1u | (TS_MODE_F64 << 1); n_child = 2; }
                     } else if (need_refl) {
                         c_ent[0] = ent;
                         n_child = 1;
-                        if (have_inter) {
-                            node_kind = WF_COMBINE_INTER;
-                            B.node_ratio[nid] = ratio;
-                            B.node_parent[nid] = parent;
-                            wf_deliver(B, nid, 0u, inter);
-                            c_parent[0] = nid; c_slot[0] = 1u;
+                        if (have_inter) {      /* the opaque surface colour waits in the node; the reflection is combined with it on arrival */
+                            node_kind = TS_COMBINE_INTER;
+                            N->ratio = ratio; N->parent = parent; N->meta = node_kind | (sm << 8);
+                            N->c1[0] = inter.r; N->c1[1] = inter.g; N->c1[2] = inter.b; N->c1[3] = inter.a;
+                            c_parent[0] = nid; c_sm[0] = 1u | (TS_MODE_INTER << 1);
                         } else {   /* the reflection colour is the result (surface.rs:153-154): the child reports to our parent */
-                            c_parent[0] = parent; c_slot[0] = slot;
+                            c_parent[0] = parent; c_sm[0] = sm;
                         }
                     } else {
                         if (!have_inter) cnt.errors++;            /* the reference panics here (surface.rs:154) */
-                        wf_deliver(B, parent, slot, inter);
+                        ts_deliver(B.nodes, parent, sm, inter, cnt, rgba, point_rgb);
                     }
                 }
-                B.node_meta[nid] = node_kind | (slot << 8);
+                B.node_kind[nid] = (uint8_t)node_kind;
             }
             /* children with no depth left (or plain misses) only sample the background
              * (universe/mod.rs:157,183): one code site for all of them */
             WF_STAMP(5);
             /* (a lane's children are either all background-only or all queued: the miss case has one child) */
-            const bool bg_only = n_child != 0 && ((c_slot[0] & 2u) != 0 || child_depth == 0);
+            const bool bg_only = n_child != 0 && (bg_miss || child_depth == 0);
             const uint32_t n_queue = bg_only ? 0u : n_child;
 #pragma unroll 1
             for (uint32_t k = 0; k < 2; k++) {      /* constant indices only: a run-time indexed private array would live in scratch */
@@ -576,9 +556,9 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
 #pragma unroll
                     for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
 #ifdef EU_DEBUG_SKIP
-                    wf_deliver(B, k ? c_parent[1] : c_parent[0], (k ? c_slot[1] : c_slot[0]) & 1u, (dbg_shade & 1u) ? Rgba{0.1, 0.2, 0.3, 1.0} : wf_background<D>(S, dd, cnt));
+                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], (dbg_shade & 1u) ? Rgba{0.1, 0.2, 0.3, 1.0} : ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
 #else
-                    wf_deliver(B, k ? c_parent[1] : c_parent[0], (k ? c_slot[1] : c_slot[0]) & 1u, wf_background<D>(S, dd, cnt));
+                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
 #endif
                 }
             }
@@ -587,11 +567,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             const uint32_t pos0 = wf_append_local(&seg_fill, n_queue, pos1);
             if (n_queue >= 1) {
                 if (pos0 >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
-                else wf_store_ray<D>(B, outb, out_base + pos0, c_o[0], c_d[0], c_parent[0], c_ent[0] | (c_slot[0] << 16));
+                else wf_store_ray<D>(B, outb, out_base + pos0, c_o[0], c_d[0], c_parent[0], c_ent[0] | (c_sm[0] << 16));
             }
             if (n_queue >= 2) {
                 if (pos1 >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
-                else wf_store_ray<D>(B, outb, out_base + pos1, c_o[1], c_d[1], c_parent[1], c_ent[1] | (c_slot[1] << 16));
+                else wf_store_ray<D>(B, outb, out_base + pos1, c_o[1], c_d[1], c_parent[1], c_ent[1] | (c_sm[1] << 16));
             }
             WF_STAMP(7);
             }   /* sub */
@@ -610,53 +590,29 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     wf_flush_counters(counters, cnt);
 }
 
-/* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes */
+/* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes
+ * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
+ * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass */
 template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters) {
+__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
     LaneCounters cnt = {0, 0, 0, 0};
-    const uint32_t node_base = B.npix + gen * B.ray_cap;
+    const uint32_t node_base = gen * B.ray_cap;
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     {
         for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
             const uint32_t nid = node_base + wf_map_index(pref, B.n_seg, B.seg_cap, v);
-            const uint32_t meta = B.node_meta[nid];
-            const uint32_t kind = meta & 0xffu;
-            if (kind == WF_NONE) continue;
-            const double *ch = B.node_child + (size_t)nid * 8;
-            Rgba c0 = {ch[0], ch[1], ch[2], ch[3]};
-            Rgba res;
-            if (kind == WF_COMBINE_INTER) {                                            /* surface.rs:159-161 */
-                const Rgba c1 = {ch[4], ch[5], ch[6], ch[7]};
-                res = combine_palette_color(c1, c0, B.node_ratio[nid]);
-            } else {
-                /* surface_palette.over(transition_palette), both re-quantised to u8 (surface.rs:104-114) */
-                const uint32_t tpx = to_pixel4(c0, cnt);
-                const Rgba inter = blend_rgba(EU_BL_OVER, new_u8(B.node_px[nid]), new_u8(tpx));
-                if (kind == WF_OVER) res = inter;
-                else {
-                    const Rgba c1 = {ch[4], ch[5], ch[6], ch[7]};
-                    res = combine_palette_color(c1, inter, B.node_ratio[nid]);
-                }
+            const uint32_t kind = B.node_kind[nid];
+            if (kind == TS_NONE) continue;
+            const EuTsNode *N = B.nodes + nid;
+            Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
+            if (kind != TS_COMBINE_INTER) {
+                const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
+                res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
             }
-            wf_deliver(B, B.node_parent[nid], (meta >> 8) & 1u, res);
+            ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
         }
-    }
-    wf_flush_counters(counters, cnt);
-}
-
-/* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_final_kernel(EuWfBuffers B, uint32_t root_base, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
-    LaneCounters cnt = {0, 0, 0, 0};
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
-        if ((B.node_meta[p] & 0xffu) != WF_ROOT) continue;
-        const double *ch = B.node_child + (size_t)p * 8;
-        const Rgba ret = {ch[0], ch[1], ch[2], ch[3]};
-        const Rgba white = {1.0, 1.0, 1.0, 1.0};
-        const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(ret), into_premultiplied(white)));
-        rgba[p + root_base] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
-        if (point_rgb) { point_rgb[0] = out.r; point_rgb[1] = out.g; point_rgb[2] = out.b; }
     }
     wf_flush_counters(counters, cnt);
 }
