@@ -114,6 +114,20 @@ struct eu_renderer {
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
     uint32_t wf_depth = 0;                   /* deepest max_depth the node slots are sized for */
+    /* FINISH step: once a generation holds fewer than wf_finish_rays rays, the stream kernel (trace_stream.h, import mode) takes
+     * that generation's queue over and finishes those rays and all their descendants in ONE launch; the generation to hand over at
+     * is learnt from the previous frame's queue lengths (read back asynchronously), so a wrong guess costs time, never correctness */
+    EuTsPool wf_fin[WF_MAX_STREAMS] = {};
+    unsigned wf_fin_grid = 0;
+    uint32_t wf_finish_rays = 0;             /* EU_WF_FINISH_RAYS; 0 = never hand over, the default: measured slower */
+    uint32_t wf_handover[WF_MAX_STREAMS] = {};      /* generation the next frame hands over at (>= max_depth: no finish step) */
+    EuDevCounters *wf_fin_counters[WF_MAX_STREAMS] = {};   /* the finish kernel's own segment / node-chunk counters */
+    uint32_t *wf_d_totals[WF_MAX_STREAMS] = {};     /* rays per generation of the band most recently traced with this buffer set */
+    uint32_t *wf_h_totals[WF_MAX_STREAMS] = {};     /* pinned host copy */
+    hipEvent_t wf_totals_ready[WF_MAX_STREAMS] = {};
+    bool wf_totals_pending[WF_MAX_STREAMS] = {};
+    uint32_t wf_totals_handover[WF_MAX_STREAMS] = {};   /* the hand-over generation of the frame the pending totals describe */
+    size_t wf_totals_pixels[WF_MAX_STREAMS] = {};
     hipStream_t wf_stream[WF_MAX_STREAMS] = {};
     hipEvent_t wf_fork = nullptr, wf_join[WF_MAX_STREAMS] = {};
     int wf_n_streams = 2;                    /* EU_WF_STREAMS (1 = everything on the caller's stream) */
@@ -191,6 +205,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         }
         if (const char *k = getenv("EU_TS_NODE_FACTOR")) r->ts_node_factor = atof(k);
         if (const char *k = getenv("EU_TS_GRID")) r->ts_grid_limit = (unsigned)atoi(k);
+        if (const char *k = getenv("EU_WF_FINISH_RAYS")) r->wf_finish_rays = (uint32_t)strtoul(k, nullptr, 10);
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
         r->wf_n_streams = (h.flags & 1u) ? 2 : 1;      /* branching scenes: two band pipelines fill each other's kernel tails (measured: +8 %); others: -5 % */
@@ -229,6 +244,10 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
     for (void *p : r->ts_allocs) (void)hipFree(p);
+    for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) {
+        if (r->wf_h_totals[k]) (void)hipHostFree(r->wf_h_totals[k]);
+        if (r->wf_totals_ready[k]) (void)hipEventDestroy(r->wf_totals_ready[k]);
+    }
     for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { if (r->wf_stream[k]) (void)hipStreamDestroy(r->wf_stream[k]); if (r->wf_join[k]) (void)hipEventDestroy(r->wf_join[k]); }
     if (r->wf_fork) (void)hipEventDestroy(r->wf_fork);
     if (r->d_scene) (void)hipFree(r->d_scene);
@@ -321,11 +340,43 @@ static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth) {
     if ((rc = alloc((void **)&B.hit_ent, ray_cap * 4))) return rc;
     /* node ids are static: pixel roots, then generation g's queue slot q at pixels + g*ray_cap + q
      * (only the slots that hold rays are ever touched) */
-    if ((rc = alloc((void **)&B.nodes, node_cap * sizeof(EuTsNode)))) return rc;
+    /* the finish step's pool: its node chunks lie behind the pipeline's slots in the same array (one id space for deliveries) */
+    EuTsPool &F = r->wf_fin[set];
+    memset(&F, 0, sizeof F);
+    const unsigned fin_grid = (unsigned)r->num_cus * 2u;
+    const uint32_t fin_nch = EU_TS_NCH;
+    const size_t chunk_base = (node_cap + EU_TS_NCN - 1) / EU_TS_NCN;
+    const size_t fin_rays = (size_t)r->wf_finish_rays < ray_cap ? (size_t)r->wf_finish_rays : ray_cap;      /* the hand-over generation holds at most this many */
+    const size_t fin_chunks = (fin_rays * 6) / EU_TS_NCN + (size_t)fin_grid * (EU_MAX_DEPTH + 2) + 1;
+    if ((chunk_base + fin_chunks) * (size_t)EU_TS_NCN > 0xfffffff0ull) { r->err = "frame too large for 32-bit node indices; render it in row tiles"; return EU_ERR_CAPACITY; }
+    if ((rc = alloc((void **)&B.nodes, (chunk_base + fin_chunks) * EU_TS_NCN * sizeof(EuTsNode)))) return rc;
     if ((rc = alloc((void **)&B.node_kind, node_cap))) return rc;
     if ((rc = alloc((void **)&B.seg_count, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4))) return rc;
+    HIP_TRY(hipMemset(B.seg_count, 0, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4));
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
+    if (r->wf_finish_rays) {
+        const size_t chunks = (size_t)fin_grid * fin_nch;
+        if ((rc = alloc((void **)&F.ray_od, chunks * 2 * D * EU_TS_CH * sizeof(double)))) return rc;
+        if ((rc = alloc((void **)&F.ray_parent, chunks * EU_TS_CH * 4))) return rc;
+        if ((rc = alloc((void **)&F.ray_aux, chunks * EU_TS_CH * 4))) return rc;
+        if ((rc = alloc((void **)&F.hit_t, (size_t)fin_grid * EU_TS_CH * 8))) return rc;
+        if ((rc = alloc((void **)&F.hit_code, (size_t)fin_grid * EU_TS_CH * 4))) return rc;
+        if ((rc = alloc((void **)&F.nchunk_prev, fin_chunks * 4))) return rc;
+        if ((rc = alloc((void **)&F.wg_counters, (size_t)fin_grid * EU_TS_ROW * sizeof(unsigned long long)))) return rc;
+        if ((rc = alloc((void **)&r->wf_d_totals[set], (EU_MAX_DEPTH + 2) * 4))) return rc;
+        if ((rc = alloc((void **)&r->wf_fin_counters[set], sizeof(EuDevCounters)))) return rc;
+        F.nodes = B.nodes; F.n_node_chunks = (uint32_t)fin_chunks; F.node_chunk_base = (uint32_t)chunk_base; F.n_wg = fin_grid; F.nch = fin_nch;
+        /* nchunk_prev is indexed by the global chunk id */
+        F.nchunk_prev -= chunk_base;
+        r->wf_fin_grid = fin_grid;
+        if (!r->wf_h_totals[set]) {
+            HIP_TRY(hipHostMalloc((void **)&r->wf_h_totals[set], (EU_MAX_DEPTH + 2) * 4, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&r->wf_totals_ready[set], hipEventDisableTiming));
+        }
+        r->wf_totals_pending[set] = false;
+        r->wf_handover[set] = EU_MAX_DEPTH + 1;      /* the first frame runs every generation and learns their sizes */
+    }
     }
     if (!r->wf_stream[0]) {
         for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { HIP_TRY(hipStreamCreateWithFlags(&r->wf_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&r->wf_join[k], hipEventDisableTiming)); }
@@ -340,6 +391,50 @@ template <class K> static int wf_grid(eu_renderer *r, K kern, size_t lds_bytes, 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, EU_WF_BLOCK, lds_bytes));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     grid = (unsigned)(r->num_cus * blocks_per_cu);
+    return EU_OK;
+}
+
+/* rays per generation of one buffer set's queues (read back asynchronously: the next frame's hand-over generation) */
+__global__ void eu_wf_totals_kernel(EuWfBuffers B, uint32_t *__restrict__ out) {
+    __shared__ uint32_t acc[EU_MAX_DEPTH + 2];
+    if (threadIdx.x < EU_MAX_DEPTH + 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t g = 0; g <= EU_MAX_DEPTH; g++) {
+        uint32_t s = 0;
+        for (uint32_t k = threadIdx.x; k < B.n_seg; k += blockDim.x) s += B.seg_count[g * B.n_seg + k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&acc[g], s);
+    }
+    __syncthreads();
+    if (threadIdx.x <= EU_MAX_DEPTH) out[threadIdx.x] = acc[threadIdx.x];
+}
+
+/* the FINISH step: the stream kernel takes over the queue of generation `gen` and everything below it */
+template <int D, int HSCAP, bool LDS>
+static int wf_launch_finish(eu_renderer *r, hipStream_t stream, int set, uint32_t gen, const EuDevCamera &dc, const EuDevFrame &df, const EuWfBuffers &B, uint32_t *rgba, double *point) {
+    auto kern = eu_ts_kernel<D, HSCAP, LDS>;
+    uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    const size_t hs_bytes = HSCAP == 0 ? (size_t)(EU_TS_BLOCK / 64) * hs_cap * 64 * 12 : 0;
+    const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(double) * EU_TS_BLOCK;
+    const size_t shade_bytes = (LDS ? (size_t)r->scene_words * 8 : 0) + color_lds;
+    const size_t lds_bytes = hs_bytes > shade_bytes ? hs_bytes : shade_bytes;
+    int blocks_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, EU_TS_BLOCK, lds_bytes));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    unsigned grid = (unsigned)(r->num_cus * blocks_per_cu);
+    if (grid > r->wf_fin_grid) grid = r->wf_fin_grid;
+    EuTsParams prm;
+    memset(&prm, 0, sizeof prm);
+    prm.scene_g = r->d_scene; prm.scene_words = r->scene_words; prm.hs_cap = hs_cap;
+    prm.cam = dc; prm.fr = df; prm.P = r->wf_fin[set];
+    prm.counters = r->wf_fin_counters[set]; prm.rgba = rgba; prm.hit_t_aov = nullptr; prm.point_rgb = point;
+    prm.import_gen = gen; prm.imp_n_seg = B.n_seg; prm.imp_seg_cap = B.seg_cap; prm.imp_ray_cap = B.ray_cap;
+    prm.imp_ray_od = B.ray_od[gen & 1u]; prm.imp_ray_parent = B.ray_parent[gen & 1u]; prm.imp_ray_aux = B.ray_aux[gen & 1u];
+    prm.imp_seg_count = B.seg_count + (size_t)gen * B.n_seg; prm.imp_seg_count_rows = B.seg_count;
+    prm.stats_counters = r->d_counters;
+    HIP_TRY(hipMemsetAsync(r->wf_fin_counters[set], 0, sizeof(EuDevCounters), stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(EU_TS_BLOCK), lds_bytes, stream, prm);
+    HIP_TRY(hipGetLastError());
     return EU_OK;
 }
 
@@ -400,16 +495,43 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
             B.npix = df.band_rows * df.width;
         }
         const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
+        /* hand-over generation of this band: from the queue lengths of the last frame traced with this buffer set, if they have arrived */
+        uint32_t handover = dc.max_depth;
+        if (r->wf_finish_rays && !df.single_pixel) {
+            if (r->wf_totals_pending[set] && hipEventQuery(r->wf_totals_ready[set]) == hipSuccess) {
+                r->wf_totals_pending[set] = false;
+                const uint32_t known = r->wf_totals_handover[set];      /* generations 0..known were traced (or handed over) by the pipeline: their lengths are exact */
+                uint32_t hnew = known + 1;
+                for (uint32_t g = 1; g <= known && g <= EU_MAX_DEPTH; g++) if (r->wf_h_totals[set][g] < r->wf_finish_rays) { hnew = g; break; }
+                r->wf_handover[set] = r->wf_totals_pixels[set] == (size_t)B.npix ? hnew : EU_MAX_DEPTH + 1;
+            } else if (hipGetLastError() != hipSuccess) { /* hipErrorNotReady from the query: nothing to report */ }
+            handover = r->wf_handover[set] < dc.max_depth ? r->wf_handover[set] : dc.max_depth;
+            if (handover < 1) handover = 1;
+        }
         hipLaunchKernelGGL(eu_wf_gen_kernel<D>, dim3(g_prod), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, dc, df, B, r->d_counters, rgba, hit_t, point);
-        for (uint32_t g = 0; g < dc.max_depth; g++) {
+        for (uint32_t g = 0; g < handover; g++) {
             if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, r->d_scene, r->scene_words | dbg_skip, hs_cap, g, df.root_base, B, r->d_counters, hit_t);
             else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 16u, g, df.root_base, B, r->d_counters, hit_t);
             else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, r->d_scene, r->scene_words, 96u, g, df.root_base, B, r->d_counters, hit_t);
             if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), (size_t)r->scene_words * 8 + color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters, rgba, point);
             else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), color_lds, stream, r->d_scene, r->scene_words, g, dc.max_depth | r->dbg_skip_shade, df.time_s, B, r->d_counters, rgba, point);
         }
-        for (uint32_t g = dc.max_depth; g-- > 0;)
+        if (handover < dc.max_depth) {
+            int frc;
+            if (hs_lds) frc = shade_lds ? wf_launch_finish<D, 0, true>(r, stream, set, handover, dc, df, B, rgba, point) : wf_launch_finish<D, 0, false>(r, stream, set, handover, dc, df, B, rgba, point);
+            else frc = shade_lds ? wf_launch_finish<D, 96, true>(r, stream, set, handover, dc, df, B, rgba, point) : wf_launch_finish<D, 96, false>(r, stream, set, handover, dc, df, B, rgba, point);
+            if (frc != EU_OK) return frc;
+        }
+        for (uint32_t g = handover; g-- > 0;)
             hipLaunchKernelGGL(eu_wf_resolve_kernel<D>, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, B, r->d_counters, rgba, point);
+        if (r->wf_finish_rays && !df.single_pixel && !r->wf_totals_pending[set]) {      /* this band's queue lengths, for the next frame */
+            hipLaunchKernelGGL(eu_wf_totals_kernel, dim3(1), dim3(256), 0, stream, B, r->wf_d_totals[set]);
+            HIP_TRY(hipMemcpyAsync(r->wf_h_totals[set], r->wf_d_totals[set], (EU_MAX_DEPTH + 1) * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(r->wf_totals_ready[set], stream));
+            r->wf_totals_pending[set] = true;
+            r->wf_totals_handover[set] = handover;
+            r->wf_totals_pixels[set] = (size_t)B.npix;
+        }
         if (df.single_pixel) break;
     }
     if (two_streams) {      /* join */
@@ -478,6 +600,7 @@ static int ts_launch(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, 
     prm.scene_g = r->d_scene; prm.scene_words = r->scene_words; prm.hs_cap = hs_cap;
     prm.cam = dc; prm.fr = df; prm.P = r->ts;
     prm.counters = r->d_counters; prm.rgba = rgba; prm.hit_t_aov = hit_t; prm.point_rgb = point;
+    prm.import_gen = 0xffffffffu;      /* frame mode: the rays come from the camera */
     hipLaunchKernelGGL(kern, dim3(grid), dim3(EU_TS_BLOCK), lds_bytes, stream, prm);
     HIP_TRY(hipGetLastError());
     r->ts_grid_last = grid;

@@ -71,7 +71,7 @@ struct EuTsPool {
     uint32_t *nchunk_prev;      /* [n_node_chunks] previous chunk of the same workgroup and generation */
     unsigned long long *wg_counters;   /* [n_wg][EU_TS_ROW] */
     uint32_t n_node_chunks, n_wg;
-    uint32_t nch, pad;          /* ray chunks per workgroup (<= EU_TS_NCH): 3 per generation of the frame's max_depth + 4 */
+    uint32_t nch, node_chunk_base;   /* node chunk ids handed out start here (import mode: the pool lies behind the wavefront pipeline's slots in one array) */          /* ray chunks per workgroup (<= EU_TS_NCH): 3 per generation of the frame's max_depth + 4 */
 };
 
 struct TsState {                /* per workgroup, LDS */
@@ -81,6 +81,7 @@ struct TsState {                /* per workgroup, LDS */
     uint32_t ready[EU_TS_NCH], n_ready;       /* full chunks: local chunk | generation << 8; the top is the deepest */
     uint32_t free_list[EU_TS_NCH], n_free;
     uint32_t work, cur_chunk, cur_gen, cur_count, cur_tile, next_tile;
+    uint32_t imp_off, imp_count;               /* import mode: progress inside the queue segment cur_tile */
     uint32_t app_pos, app_chunk[3];           /* ray append stream of the next generation */
     uint32_t napp_pos, napp_chunk[2];         /* node append stream of this generation */
     uint32_t hist[EU_TS_KEYS], offs[EU_TS_KEYS];
@@ -127,7 +128,7 @@ EU_DEV void ts_close_append(TsState &st, uint32_t gen) {
 EU_DEV uint32_t ts_node_chunk_alloc(TsState &st, EuDevCounters *counters, const EuTsPool &P) {
     const uint32_t id = (uint32_t)atomicAdd(&counters->node_chunks, 1ull);
     if (id >= P.n_node_chunks) { st.work = TS_WORK_ABORT; return 0; }
-    return id;
+    return P.node_chunk_base + id;
 }
 EU_DEV void ts_open_nodes(TsState &st, uint32_t gen, EuDevCounters *counters, const EuTsPool &P) {
     if (st.node_head[gen] == EU_TS_NONE) {
@@ -155,25 +156,43 @@ EU_DEV void ts_close_nodes(TsState &st, uint32_t gen, const EuTsPool &P) {
 }
 
 /* thread 0: put the finished step's output away, then decide what the workgroup does next */
-EU_DEV void ts_schedule(TsState &st, uint32_t max_depth, uint32_t n_work_tiles, EuDevCounters *counters, const EuTsPool &P) {
+/* Where a workgroup's rays come from.  Frame mode: 256-pixel tiles of the frame (camera rays, generation 0).  Import mode (the
+ * wavefront pipeline's FINISH step): the segments of that pipeline's queue of generation `gen0`, taken over 256 rays at a time;
+ * the workgroup then finishes those rays and all their descendants, and delivers into the pipeline's nodes and pixels. */
+struct TsSource {
+    uint32_t n_tiles;           /* work tiles of the frame | queue segments */
+    uint32_t gen0;              /* generation the incoming rays belong to (0 | the hand-over generation) */
+    const uint32_t *seg_count;  /* import mode: rays in each segment of the queue; nullptr in frame mode */
+};
+
+EU_DEV void ts_schedule(TsState &st, uint32_t max_depth, const TsSource &src, EuDevCounters *counters, const EuTsPool &P) {
     if (st.work == TS_WORK_PROCESS) {
         if (st.cur_gen + 1 < max_depth) ts_close_append(st, st.cur_gen + 1);
         ts_close_nodes(st, st.cur_gen, P);
         st.free_list[st.n_free++] = st.cur_chunk;
-    } else if (st.work == TS_WORK_GENERATE && max_depth > 0) ts_close_append(st, 0);
+    } else if (st.work == TS_WORK_GENERATE && max_depth > src.gen0) ts_close_append(st, src.gen0);
     if (st.work == TS_WORK_ABORT) return;
     if (st.n_ready) {                               /* the deepest full chunk */
         const uint32_t e = st.ready[--st.n_ready];
         st.work = TS_WORK_PROCESS; st.cur_chunk = e & 0xffu; st.cur_gen = e >> 8; st.cur_count = EU_TS_CH;
-    } else if (st.next_tile < n_work_tiles) {       /* more pixels */
+    } else if (!src.seg_count && st.next_tile < src.n_tiles) {       /* more pixels */
         st.work = TS_WORK_GENERATE; st.cur_tile = st.next_tile;
-    } else {                                        /* flush: the shallowest open chunk (its children top up the deeper ones) */
+    } else {
         st.work = TS_WORK_DONE;
-        for (uint32_t g = 0; g < max_depth; g++) {
-            if (st.open_fill[g]) {
-                st.work = TS_WORK_PROCESS; st.cur_chunk = st.open_chunk[g]; st.cur_gen = g; st.cur_count = st.open_fill[g];
-                st.open_chunk[g] = EU_TS_NONE; st.open_fill[g] = 0;
-                break;
+        if (src.seg_count) {                        /* more queued rays to take over?  (skips empty segments) */
+            while (st.imp_off >= st.imp_count && st.next_tile < src.n_tiles) {
+                st.cur_tile = st.next_tile; st.imp_off = 0; st.imp_count = src.seg_count[st.cur_tile];
+                st.next_tile = (uint32_t)atomicAdd(&counters->next_item, 1ull);
+            }
+            if (st.imp_off < st.imp_count) st.work = TS_WORK_GENERATE;
+        }
+        if (st.work == TS_WORK_DONE) {              /* flush: the shallowest open chunk (its children top up the deeper ones) */
+            for (uint32_t g = 0; g < max_depth; g++) {
+                if (st.open_fill[g]) {
+                    st.work = TS_WORK_PROCESS; st.cur_chunk = st.open_chunk[g]; st.cur_gen = g; st.cur_count = st.open_fill[g];
+                    st.open_chunk[g] = EU_TS_NONE; st.open_fill[g] = 0;
+                    break;
+                }
             }
         }
     }
@@ -181,7 +200,7 @@ EU_DEV void ts_schedule(TsState &st, uint32_t max_depth, uint32_t n_work_tiles, 
         if (st.cur_gen + 1 < max_depth) ts_open_append(st, st.cur_gen + 1);
         ts_open_nodes(st, st.cur_gen, counters, P);
         for (uint32_t k = 0; k < EU_TS_KEYS; k++) st.hist[k] = 0;
-    } else if (st.work == TS_WORK_GENERATE && max_depth > 0) ts_open_append(st, 0);
+    } else if (st.work == TS_WORK_GENERATE && max_depth > src.gen0) ts_open_append(st, src.gen0);
 }
 
 /* Everything the kernel is told, as ONE by-value argument.  The kernel never touches the argument itself: every phase reads
@@ -198,6 +217,12 @@ struct EuTsParams {
     EuDevCounters *counters;
     uint32_t *rgba;
     double *hit_t_aov, *point_rgb;
+    /* import mode (import_gen != 0xffffffff): the wavefront pipeline's queue of that generation */
+    uint32_t import_gen, imp_n_seg, imp_seg_cap, imp_ray_cap;
+    const double *imp_ray_od;
+    const uint32_t *imp_ray_parent, *imp_ray_aux, *imp_seg_count;
+    uint32_t *imp_seg_count_rows;      /* the pipeline's [EU_MAX_DEPTH + 1][n_seg] table: rows behind import_gen are cleared (they describe an older frame) */
+    EuDevCounters *stats_counters;     /* not null: add rays / background samples / would-panic counts (and an abort) to the pipeline's accounting */
 };
 typedef const EuTsParams __attribute__((address_space(4))) *TsParamsPtr;
 EU_DEV TsParamsPtr ts_params() {
@@ -209,8 +234,15 @@ EU_DEV EuTsPool ts_pool(TsParamsPtr q) {
     EuTsPool P;
     P.ray_od = q->P.ray_od; P.ray_parent = q->P.ray_parent; P.ray_aux = q->P.ray_aux; P.hit_t = q->P.hit_t; P.hit_code = q->P.hit_code;
     P.nodes = q->P.nodes; P.nchunk_prev = q->P.nchunk_prev; P.wg_counters = q->P.wg_counters;
-    P.n_node_chunks = q->P.n_node_chunks; P.n_wg = q->P.n_wg; P.nch = q->P.nch; P.pad = 0;
+    P.n_node_chunks = q->P.n_node_chunks; P.n_wg = q->P.n_wg; P.nch = q->P.nch; P.node_chunk_base = q->P.node_chunk_base;
     return P;
+}
+EU_DEV TsSource ts_source(TsParamsPtr q) {
+    TsSource src;
+    const uint32_t ig = q->import_gen;
+    if (ig == 0xffffffffu) { src.n_tiles = (q->fr.n_tiles + 3u) / 4u; src.gen0 = 0; src.seg_count = nullptr; }
+    else { src.n_tiles = q->imp_n_seg; src.gen0 = ig; src.seg_count = q->imp_seg_count; }
+    return src;
 }
 
 template <int D> EU_DEV void ts_store_ray(const EuTsPool &P, const TsState &st, uint32_t pos, const double *o, const double *d, uint32_t parent, uint32_t aux) {
@@ -304,6 +336,29 @@ template <int D> EU_DEV void ts_generate(TsState &st, LaneCounters &cnt, int cam
     const uint32_t pos = ts_reserve(&st.app_pos, have_ray ? 1u : 0u, second);
     if (have_ray) ts_store_ray<D>(P, st, pos, o, d, out_idx, ent_u | ((uint32_t)(TS_MODE_ROOT << 1) << 16));
     if (tid == 0) st.next_tile = nt;
+}
+
+/* ---------------------------------------------------------------- import mode: up to 256 rays of the queue segment cur_tile move into this
+ * workgroup's open chunk of their generation (records as they are: the parent is a node or pixel of the wavefront pipeline) */
+template <int D> EU_DEV void ts_import(TsState &st) {
+    TsParamsPtr q = ts_params();
+    const uint32_t tid = threadIdx.x;
+    const EuTsPool P = ts_pool(q);
+    const uint32_t i = st.imp_off + tid;
+    const bool have = i < st.imp_count;
+    const size_t cap = q->imp_ray_cap, slot = (size_t)st.cur_tile * q->imp_seg_cap + i;
+    double o[D], d[D];
+    uint32_t parent = 0, aux = 0;
+    if (have) {
+        const double *od = q->imp_ray_od;
+#pragma unroll
+        for (int k = 0; k < D; k++) { o[k] = od[(size_t)k * cap + slot]; d[k] = od[(size_t)(D + k) * cap + slot]; }
+        parent = q->imp_ray_parent[slot]; aux = q->imp_ray_aux[slot];
+    }
+    uint32_t second;
+    const uint32_t pos = ts_reserve(&st.app_pos, have ? 1u : 0u, second);
+    if (have) ts_store_ray<D>(P, st, pos, o, d, parent, aux);
+    if (tid == 0) st.imp_off += EU_TS_BLOCK;
 }
 
 /* ---------------------------------------------------------------- trace_closest (universe/mod.rs:85-147) for the rays of the current chunk:
@@ -566,8 +621,14 @@ __global__ __launch_bounds__(EU_TS_BLOCK, EU_TS_WAVES) void eu_ts_kernel(EuTsPar
         __syncthreads();
         if (tid == 0) {
             st.n_ready = 0; st.n_free = nch; st.node_spare = EU_TS_NONE; st.work = TS_WORK_DONE;
+            st.imp_off = 0; st.imp_count = 0;
             st.next_tile = (uint32_t)atomicAdd(&q->counters->next_item, 1ull);
-            ts_schedule(st, q->cam.max_depth, (q->fr.n_tiles + 3u) / 4u, q->counters, ts_pool(q));
+            if (q->import_gen != 0xffffffffu && blockIdx.x == 0) {      /* queue lengths behind the hand-over generation belong to an older frame */
+                uint32_t *rows = q->imp_seg_count_rows;
+                const uint32_t n_seg = q->imp_n_seg;
+                for (uint32_t k = (q->import_gen + 1) * n_seg; k < (EU_MAX_DEPTH + 1) * n_seg; k++) rows[k] = 0u;
+            }
+            ts_schedule(st, q->cam.max_depth, ts_source(q), q->counters, ts_pool(q));
         }
         __syncthreads();
     }
@@ -576,7 +637,8 @@ __global__ __launch_bounds__(EU_TS_BLOCK, EU_TS_WAVES) void eu_ts_kernel(EuTsPar
         const uint32_t work = st.work;
         if (work == TS_WORK_DONE || work == TS_WORK_ABORT) break;
         if (work == TS_WORK_GENERATE) {
-            ts_generate<D>(st, cnt, cam_ent);
+            if (ts_params()->import_gen != 0xffffffffu) ts_import<D>(st);
+            else ts_generate<D>(st, cnt, cam_ent);
             __syncthreads();
             TS_CLK(0);
 #ifdef EU_TS_PROFILE
@@ -616,7 +678,7 @@ __global__ __launch_bounds__(EU_TS_BLOCK, EU_TS_WAVES) void eu_ts_kernel(EuTsPar
         }
         if (tid == 0) {
             TsParamsPtr q = ts_params();
-            ts_schedule(st, q->cam.max_depth, (q->fr.n_tiles + 3u) / 4u, q->counters, ts_pool(q));
+            ts_schedule(st, q->cam.max_depth, ts_source(q), q->counters, ts_pool(q));
         }
         __syncthreads();
         TS_CLK(4);
@@ -643,6 +705,14 @@ __global__ __launch_bounds__(EU_TS_BLOCK, EU_TS_WAVES) void eu_ts_kernel(EuTsPar
     {
         TsParamsPtr q = ts_params();
         unsigned long long *row = q->P.wg_counters + (size_t)blockIdx.x * EU_TS_ROW;
+        if (q->stats_counters) {      /* the wavefront pipeline's accounting: a few atomics per workgroup */
+            EuDevCounters *c = q->stats_counters;
+            if (tid == 0 && st.wg_cnt[0]) atomicAdd(&c->rays, st.wg_cnt[0]);
+            if (tid == 1 && st.wg_cnt[1]) atomicAdd(&c->bg_samples, st.wg_cnt[1]);
+            if (tid == 2 && st.wg_cnt[2]) atomicAdd(&c->nan_pixels, st.wg_cnt[2]);
+            if (tid == 3 && st.wg_cnt[3]) atomicAdd(&c->errors, st.wg_cnt[3]);
+            if (tid == 4 && st.work == TS_WORK_ABORT) atomicAdd(&c->overflow, 1ull);
+        }
         if (tid < 4) row[tid] = st.wg_cnt[tid];
         if (tid == 4) row[4] = st.work == TS_WORK_ABORT ? 1ull : 0ull;
 #ifdef EU_TS_PROFILE

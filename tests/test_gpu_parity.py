@@ -381,3 +381,29 @@ def test_render_multi_on_one_device(ranks, W, H, rows):
     if ranks == 2 and rows is None:
         orgb, _, ost = load_scene_file(path).render(W, H, max_depth=6)
         assert np.array_equal(multi.data, orgb) and multi.stats["rays"] == ost["rays"]
+
+
+@pytest.mark.parametrize("scene,w,h,depth,finish_rays", [("3d_room.json", 320, 180, 8, "1000000000"), ("3d_room.json", 320, 180, 8, "60000"),
+                                                         ("3d_hallways.json", 320, 180, 12, "20000"), ("4d_frame.json", 192, 108, 8, "1000000000"),
+                                                         ("4d_cylinders.json", 160, 90, 8, "1000"), ("3d_fresnel_2.json", 128, 128, 10, "1000000000")])
+def test_finish_step_parity(scene, w, h, depth, finish_rays, monkeypatch):
+    """The wavefront pipeline's FINISH step (small generations handed over to the stream kernel in one launch) is learnt from
+    the previous frame's queue lengths: the first frame of a renderer runs every generation, later ones hand over.  All of
+    them must equal the oracle, whatever the threshold makes the hand-over generation."""
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    monkeypatch.setenv("EU_WF_FINISH_RAYS", finish_rays)
+    path = os.path.join(SCENES, scene)
+    env = Parser().parse_file(path)
+    env.camera.max_depth = depth
+    frames = [env.render((w, h), want_hit_t=True) for _ in range(4)]
+    other = env.render((w // 2, h // 2))          # a different frame size: the learnt generation must not be used for it
+    back = env.render((w, h))
+    env.close()
+    osc = load_scene_file(path)
+    orgb, ohit, ost = osc.render(w, h, max_depth=depth, want_hit_t=True)
+    for k, f in enumerate(frames + [back]):
+        assert np.array_equal(f.data, orgb), "frame %d differs in %d bytes" % (k, int((f.data != orgb).sum()))
+        assert f.stats == {key: ost[key] for key in f.stats}, k
+    o2, _, _ = osc.render(w // 2, h // 2, max_depth=depth)
+    assert np.array_equal(other.data, o2)
