@@ -130,21 +130,60 @@ def load_traffic(workload_key):
     return load_pmc(workload_key).get("hbm_bytes_per_launch")
 
 
-# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 VALU instruction occupies its SIMD for 4 cycles
-# (16 lanes per clock; f64 FMA is full rate: 256*4*16*2*2.4e9 = 78.6 TFLOP/s)
-VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4.0
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 f64 VALU instruction occupies its SIMD for 4 cycles (16 lanes per
+# clock; f64 FMA is full rate: 256*4*16*2*2.4e9 = 78.6 TFLOP/s), a 32-bit one for 2 cycles.
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+F64_PEAK_TFLOPS = 78.6
 
 
 def valu_figure(workload_key, kernel_ms):
     """Secondary roofline (the path is f64-VALU bound, not HBM bound): wave-level VALU instructions of one frame
-    pipeline (PMC, committed) over the live kernel time, against the VALU issue peak."""
+    pipeline (PMC, committed) over the live kernel time, against the VALU issue peak.  The peak is weighted with the kernels'
+    instruction mix: cycles per instruction = 4 for the f64 share, 2 for the rest (static mix of each kernel, profiles/
+    r02_isa_mix.json, weighted with each kernel's dynamic VALU count, profiles/r02_room_pmc.json)."""
     pmc = load_pmc(workload_key)
     n = pmc.get("valu_wave_insts_per_launch")
     if not n:
         return None
+    cycles = 4.0
+    mix_src = "every VALU instruction priced at 4 cycles (no mix on file)"
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))["kernels"]
+        dyn = json.load(open(os.path.join(ROOT, "profiles", "r02_room_pmc.json")))
+        num = den = 0.0
+        for k, d in dyn["derived"].items():
+            short = k.split("<")[0]
+            if short in mix and "SQ_INSTS_VALU_per_launch" in d:
+                w = d["SQ_INSTS_VALU_per_launch"] * dyn["launches_per_frame_single_stream"].get(k, 1)
+                f = mix[short]["valu_f64_share"]
+                num += w * (4.0 * f + 2.0 * (1.0 - f))
+                den += w
+        if den:
+            cycles = num / den
+            mix_src = "profiles/r02_isa_mix.json x profiles/r02_room_pmc.json"
+    except Exception:
+        pass
+    peak = SIMD_CYCLES_PER_S / cycles / 1e9
     ach = n / (kernel_ms * 1e-3) / 1e9
-    return {"achieved": ach, "peak": VALU_PEAK_GINST_S, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GINST_S,
-            "lane_utilisation": pmc.get("valu_lane_utilisation"), "wave_insts_per_launch": n}
+    return {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak, "cycles_per_instruction": cycles,
+            "mix": mix_src, "lane_utilisation": pmc.get("valu_lane_utilisation"), "wave_insts_per_launch": n}
+
+
+def flops_figure(workload_key, rays, kernel_ms):
+    """Compute roofline: f64 operations of the reference ALGORITHM per ray, counted by the oracle's instrumented
+    build (profiles/r02_oracle_flops.json; add/sub/mul, div, sqrt and transcendental calls count 1 each), times this frame's
+    rays, over the live kernel time, against the f64 vector peak.  The kernels execute several instructions per division,
+    square root and transcendental call, so their own f64 instruction rate is higher than this figure (see `valu`)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_oracle_flops.json")))["workloads"].get(workload_key)
+    except Exception:
+        rec = None
+    if not rec:
+        return None
+    per_ray = rec["per_ray_all"]
+    ach = per_ray * rays / (kernel_ms * 1e-3) / 1e12
+    return {"per_ray": per_ray, "per_ray_breakdown": rec["per_ray"], "achieved_TFLOPs": ach, "peak": F64_PEAK_TFLOPS, "frac": ach / F64_PEAK_TFLOPS,
+            "counted_by": "oracle/libeo_oracle_flops.so on the same workload (tools/oracle_variants_report.py)"}
 
 
 def animate(args, env, scene_path):
@@ -231,7 +270,8 @@ def other_configs(torch, dev, stream, Parser):
                     "ms_per_step": dt * 1e3, "steps": steps, "rays_per_frame": int(st["rays"]),
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth))}})
+                                 "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
+                                 "flops": flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)}})
         env.close()
         del rgba, rgb
     return out
@@ -381,8 +421,8 @@ def main():
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
                        "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(workload), "kernel": "eu_wf_* frame pipeline (gen, 8x intersect+shade, 8x resolve, final)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms),
+                         "traffic": load_traffic(workload), "kernel": "eu_wf_* frame pipeline (gen, %dx intersect+shade, %dx resolve)" % (args.max_depth, args.max_depth), "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms), "flops": flops_figure(workload, rays_per_step, kernel_ms),
                          "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it"},
         }
         if cfg5 is not None:
