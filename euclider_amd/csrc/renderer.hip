@@ -114,6 +114,7 @@ struct eu_renderer {
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
     uint32_t wf_depth = 0;                   /* deepest max_depth the node slots are sized for */
+    int wf_sets = 0;                         /* buffer sets allocated */
     /* FINISH step: once a generation holds fewer than wf_finish_rays rays, the stream kernel (trace_stream.h, import mode) takes
      * that generation's queue over and finishes those rays and all their descendants in ONE launch; the generation to hand over at
      * is learnt from the previous frame's queue lengths (read back asynchronously), so a wrong guess costs time, never correctness */
@@ -304,22 +305,24 @@ static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCa
 
 
 /* ------------------------------------------------------------------ wavefront pipeline (trace_wavefront.h) */
-static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth) {
-    if (pixels <= r->wf_pixels && max_depth <= r->wf_depth) return EU_OK;
+static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth, int n_sets) {
+    if (pixels <= r->wf_pixels && max_depth <= r->wf_depth && n_sets <= r->wf_sets) return EU_OK;
     if (pixels < r->wf_pixels) pixels = r->wf_pixels;
     if (max_depth > r->wf_depth) r->wf_depth = max_depth;
+    if (n_sets > r->wf_sets) r->wf_sets = n_sets;      /* the second buffer set exists only once a frame is traced as two concurrent bands */
     for (void *p : r->wf_allocs) (void)hipFree(p);
     r->wf_allocs.clear();
     r->wf_pixels = 0;
     const int D = r->dim;
-    for (int set = 0; set < r->wf_n_streams; set++) {
+    for (int set = 0; set < r->wf_sets; set++) {
     EuWfBuffers &B = r->wf[set];
     memset(&B, 0, sizeof B);
     /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
     uint32_t n_seg = (uint32_t)r->num_cus * 3u;
     if (n_seg > EU_WF_MAX_SEG) n_seg = EU_WF_MAX_SEG;
+    if (pixels / 16 < n_seg) n_seg = pixels / 16 < 16 ? 16u : (uint32_t)(pixels / 16);      /* tiny frames, single pixels: fewer producers, small buffers */
     size_t seg_cap = ((size_t)((double)pixels * r->wf_ray_factor) + n_seg - 1) / n_seg;
-    if (seg_cap < 2048) seg_cap = 2048;        /* small frames: absorb uneven segments */
+    if (seg_cap < 1024) seg_cap = 1024;        /* small frames: absorb uneven segments */
     seg_cap = (seg_cap + 255) & ~(size_t)255;
     const size_t ray_cap = seg_cap * n_seg;
     const size_t node_cap = ray_cap * (size_t)(r->wf_depth ? r->wf_depth : 1u);      /* one slot per ray of every generation the deepest frame so far has */
@@ -459,7 +462,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
         }
     }
     const size_t band_pixels = (size_t)band_rows * df_in.width;
-    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, dc.max_depth);
+    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, dc.max_depth, two_streams ? r->wf_n_streams : 1);
     if (rc != EU_OK) return rc;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     if (r->dbg_hs_cap) hs_cap = r->dbg_hs_cap;      /* diagnostics only */

@@ -127,3 +127,81 @@ def test_scene_beyond_the_flat_format_is_refused():
     with pytest.raises(ParserError) as ei:
         Parser().parse(text)
     assert "too many shape nodes" in str(ei.value) or "16-bit" in str(ei.value)
+
+
+# ---------------------------------------------------------------- the reference's own loader tests, one by one
+# /root/reference/src/scene.rs:1503-1802 registers a one-field constructor "item" on an EMPTY parser and parses `{"item": [ 42 ]}`
+# for every primitive type.  The product's registry is fixed (the reference's own 100 constructors), so each test is mirrored
+# with the registered constructor that takes a field of that type, in the same positional form; what is read back is the value
+# as it reaches the flattened scene.  No counterpart exists for f32 (the `low_precision` feature, not built), and for u64, u16,
+# usize, i32, i64, i16, i8, isize and bool: no registered constructor has a field of those types (scene.rs:620-1408).
+def _params_of(env):
+    """the leaf-parameter doubles of the flattened scene"""
+    w = flat_words(env)
+    hdr = w[:16].view(np.uint32)
+    n_params, off_params = int(hdr[28]), int(hdr[29])
+    return w[off_params:off_params + n_params].view(np.float64)
+
+
+def test_reference_parse_float_and_f64():          # scene.rs:1503-1508, 1561-1576: {"item": [ 42 ]} -> 42.0 (an integer literal is a valid F)
+    env = Parser().parse(universe([entity({"Sphere3::new": [{"Point3::new": [42, 0.5, -7e-1]}, 3]})]))
+    p = _params_of(env)
+    assert p[0] == 42.0 and p[1] == 0.5 and p[2] == -0.7 and p[3] == 3.0 and p[4] == 9.0
+    env.close()
+
+
+def test_reference_parse_str():                    # scene.rs:1510-1525: a &str field (SetOperation's name, a texture's path)
+    two = [{"Sphere3::new": [{"Point3::new": [0, 0, 0]}, 1]}, {"Sphere3::new": [{"Point3::new": [1, 0, 0]}, 1]}]
+    for name, kind in (("Union", 8), ("Intersection", 9), ("Complement", 10), ("SymmetricDifference", 11)):
+        env = Parser().parse(universe([entity({"ComposableShape3::of": [two, {"SetOperation": [name]}]})]))
+        w = flat_words(env)
+        hdr = w[:16].view(np.uint32)
+        ops = w[int(hdr[5]):int(hdr[5]) + int(hdr[4])]
+        assert int(ops[-1]) & 0xff == kind          # the root op of the entity's shape program (flat_scene.h: EU_SH_UNION = 8 ...)
+        env.close()
+    with pytest.raises(ParserError) as e:           # a number where a &str is expected
+        Parser().parse(universe([entity({"ComposableShape3::of": [two, {"SetOperation": [42]}]})]))
+    assert e.value.kind == "TypeMismatch"
+
+
+def test_reference_parse_string():                 # scene.rs:1527-1542: a String field (LinearSpace3's legend)
+    def mat(legend):
+        return {"LinearSpace3::new": [legend, [{"ComponentTransformation3::new": [[
+            {"ComponentTransformationExpr::new": ["a * 2", "a / 2"]}, {"ComponentTransformationExpr::new": ["b", "b"]},
+            {"ComponentTransformationExpr::new": ["c", "c"]}]]}]]}
+    env = Parser().parse(universe([{"Entity3Impl::new": [{"Sphere3::new": [{"Point3::new": [0, 0, 0]}, 1]}, mat("abc"), SURF]}]))
+    env.close()
+    with pytest.raises(ParserError):                # the legend names the variables: "xyz" does not define a, b, c
+        Parser().parse(universe([{"Entity3Impl::new": [{"Sphere3::new": [{"Point3::new": [0, 0, 0]}, 1]}, mat("xyz"), SURF]}]))
+
+
+def test_reference_parse_u32_and_u8():             # scene.rs:1578-1593 (u32: the Perlin seed), 1629-1644 (u8: Rgba::new_u8)
+    surf = json.loads(json.dumps(SURF))
+    surf["ComposableSurface3"]["surface_color"] = {"surface_color_blend_3": [
+        {"surface_color_perlin_hue_seed_3": [42, 1.5, 0.25]},
+        {"surface_color_uniform_3": [{"Rgba::new_u8": [255, 51, 0, 102]}]}, {"blend_function_over": []}]}
+    ent = {"Entity3Impl::new": [{"Sphere3::new": [{"Point3::new": [0, 0, 0]}, 1]}, {"Vacuum3::new": []}, surf]}
+    env = Parser().parse(universe([ent]))
+    w = flat_words(env)
+    hdr = w[:16].view(np.uint32)
+    off_color, n_color = int(hdr[17]), int(hdr[16])
+    doubles = w[off_color:off_color + 16 * n_color].view(np.float64)
+    assert any(np.allclose(doubles[k:k + 4], [1.0, 0.2, 0.0, 0.4], rtol=0, atol=0) for k in range(len(doubles) - 3))     # u8 / 255 (scene.rs:656-661)
+    env.close()
+    for bad in (256, -1, 1.5):                      # not a u8
+        s2 = json.loads(json.dumps(surf).replace("255", json.dumps(bad), 1))
+        with pytest.raises(ParserError) as e:
+            Parser().parse(universe([{"Entity3Impl::new": [{"Sphere3::new": [{"Point3::new": [0, 0, 0]}, 1]}, {"Vacuum3::new": []}, s2]}]))
+        assert e.value.kind == "TypeMismatch"
+
+
+def test_reference_parse_vec_and_constructor():    # scene.rs:1765-1780 (Vec<T>), 1782-1802 (a constructor inside a constructor)
+    ents = [entity({"Sphere3::new": [{"Point3::new": [10 * k, 0, 0]}, 1]}) for k in range(1, 4)] + [{"Void3::new_with_vacuum": []}]
+    env = Parser().parse(universe(ents))
+    assert env.info.n_entities == 4 and env.info.n_leaves == 4      # three spheres + the void's shape
+    p = _params_of(env)
+    assert [p[5 * k] for k in range(3)] == [10.0, 20.0, 30.0]
+    env.close()
+    with pytest.raises(ParserError) as e:           # a scalar where a Vec is expected
+        Parser().parse(json.dumps({"Universe3": {"camera": {"PitchYawCamera3": []}, "entities": 5, "background": BG}}))
+    assert e.value.kind in ("TypeMismatch", "InvalidConstructor")
