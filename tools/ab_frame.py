@@ -29,5 +29,5 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 print("%-18s d%-2d %dx%d lib %-28s kernel %-9s %7.3f ms %8.1f Mray/s rays %d sha %s" % (
-    scene, depth, W, H, os.path.basename(os.environ.get("EU_LIB_PATH", "default")), os.environ.get("EU_KERNEL", "stream"),
+    scene, depth, W, H, os.path.basename(os.environ.get("EU_LIB_PATH", "default")), os.environ.get("EU_KERNEL", "wavefront"),
     dt * 1e3, img.stats["rays"] / dt / 1e6, img.stats["rays"], hashlib.sha1(img.data.tobytes()).hexdigest()[:12]))

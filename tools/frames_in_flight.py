@@ -25,5 +25,5 @@ for k in range(K): step(k)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 rays = envs[0].stats()["rays"]
-print(scene, depth, "kernel", os.environ.get("EU_KERNEL", "stream"), "envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
+print(scene, depth, "kernel", os.environ.get("EU_KERNEL", "wavefront"), "envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
 assert torch.equal(rgb[0][:H*W*3], rgb[-1][:H*W*3])
