@@ -1,0 +1,29 @@
+/*
+ * eu_real.h -- the arithmetic type of the trace path.
+ *
+ * The reference is generic over `F`: f64 by default, f32 with the cargo feature `low_precision`
+ * (/root/reference/Cargo.toml:18-20, src/main.rs:46-49).  A cargo feature makes a different binary; so does this: the same
+ * sources built with -DEU_LOW_PRECISION give libeuclider_amd_f32.so, in which every `double` of
+ * the trace path -- rays, hits, colours, scene parameters, the loader's constructor arithmetic -- is a float.  That is done the
+ * blunt way, by redefining the keyword AFTER the system headers and the public C ABI have been seen, plus:
+ *   - R(x) around every floating literal of the path, so that expressions are evaluated in F like the reference's
+ *     `<F as NumCast>::from(x)` constants, not in double with a final rounding;
+ *   - eu_f64 wherever a value stays 64-bit whatever F is: the public ABI (camera pose, hit distances, trace_screen_point's
+ *     colour), the elementary functions' internals (eu_math.h), and the LinearSpace expressions (meval evaluates in f64 and the
+ *     result is cast to F: material.rs:99-111).
+ * In the default build R(x) is x and nothing changes (checked: identical frames before and after this header was introduced).
+ */
+#ifndef EU_REAL_H
+#define EU_REAL_H
+
+typedef double eu_f64;
+#define R(x) ((double)(x))
+
+#ifdef EU_LOW_PRECISION
+#define EU_REAL_BITS 32
+#define double float
+#else
+#define EU_REAL_BITS 64
+#endif
+
+#endif

@@ -26,13 +26,13 @@
 #include <vector>
 
 #include "../../include/euclider_amd.h"
-#include "scene_host.hpp"
+#include "camera_host.hpp"      /* Camera::update stays f64 in every build: before eu_real.h */
+#include "scene_host.hpp"       /* ends with eu_real.h: from here on `double` is the path's F */
 #include "trace_device.h"
 #include "trace_megakernel.h"
 #include "trace_wavefront.h"
 #include "trace_stream.h"
 #include "trace_path.h"
-#include "camera_host.hpp"
 
 /* RGBA8 -> packed RGB8 (RawImage2d U8U8U8, universe/mod.rs:351-356): 4 pixels (16 B in, 12 B out) per thread */
 __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *__restrict__ rgb, size_t pixels) {
@@ -54,7 +54,7 @@ __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *_
 __global__ void eu_math_kernel(int fn, const double *x, const double *y, double *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double a = x[i], b = y ? y[i] : 0.0, r;
+    double a = x[i], b = y ? y[i] : R(0.0), r;
     switch (fn) {
     case 0: r = eu_acos(a); break;
     case 1: r = eu_asin(a); break;
@@ -65,7 +65,7 @@ __global__ void eu_math_kernel(int fn, const double *x, const double *y, double 
     case 6: r = sqrt(a); break;
     case 7: r = a / b; break;
     case 8: r = fmod(a, b); break;
-    default: r = 0.0;
+    default: r = R(0.0);
     }
     out[i] = r;
 }
@@ -83,8 +83,8 @@ struct eu_renderer {
     EuDevCounters *d_counters = nullptr;
     uint32_t *d_rgba = nullptr; size_t rgba_pixels = 0;      /* internal frame buffers for eu_render */
     uint8_t *d_rgb = nullptr;
-    double *d_hit = nullptr;
-    double *d_point = nullptr;
+    eu_f64 *d_hit = nullptr;
+    eu_f64 *d_point = nullptr;
     double *d_path_in = nullptr;            /* eu_trace_path: location, direction, distance */
     EuPathResult *d_path_out = nullptr;
     static constexpr int EV_RING = 64;        /* per-launch HIP event pairs, on the launch stream */
@@ -107,7 +107,7 @@ struct eu_renderer {
     size_t ts_node_chunks = 0;
     unsigned ts_grid_last = 0;               /* grid of the most recent launch: that many counter rows are valid */
     bool ts_last = false;                    /* the most recent frame went through the stream kernel */
-    double ts_node_factor = 6.0;             /* node slots per pixel (EU_TS_NODE_FACTOR); eu_render doubles it after an overflow */
+    double ts_node_factor = R(6.0);             /* node slots per pixel (EU_TS_NODE_FACTOR); eu_render doubles it after an overflow */
     unsigned ts_grid_limit = 0;              /* EU_TS_GRID: fewer workgroups than the chip holds (diagnostics) */
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
     static constexpr int WF_MAX_STREAMS = 4;
@@ -132,7 +132,7 @@ struct eu_renderer {
     hipStream_t wf_stream[WF_MAX_STREAMS] = {};
     hipEvent_t wf_fork = nullptr, wf_join[WF_MAX_STREAMS] = {};
     int wf_n_streams = 2;                    /* EU_WF_STREAMS (1 = everything on the caller's stream) */
-    double wf_ray_factor = 4.0;
+    double wf_ray_factor = R(4.0);
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass (EU_WF_BAND_PIXELS) */
     /* diagnostic switches, read from the environment once, when the renderer is created */
     uint32_t dbg_hs_cap = 0;                 /* EU_HS_CAP */
@@ -224,7 +224,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
         HIP_TRY(hipMemset(r->d_counters, 0, sizeof(EuDevCounters)));
-        HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
         return EU_OK;
     };
@@ -278,14 +278,14 @@ static int make_dev_camera(const eu_camera *cam, const eu_frame *f, EuDevCamera 
         for (int i = 0; i < D; i++) dc.right[i] = -cam->left[i];
     }
     const double w = (double)f->width, h = (double)f->height;
-    const double fov_rad = EU_PI_C * (double)cam->fov_deg / 180.0;
-    dc.dist = sqrt(w * w + h * h) / (2.0 * eu_tan(fov_rad / 2.0));
+    const double fov_rad = EU_PI_C * (double)cam->fov_deg / R(180.0);
+    dc.dist = sqrt(w * w + h * h) / (R(2.0) * eu_tan(fov_rad / R(2.0)));
     dc.max_depth = cam->max_depth;
     return EU_OK;
 }
 
 template <int D, int HSCAP, bool LDS>
-static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
+static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
     auto kern = eu_trace_kernel<D, HSCAP, LDS>;
     const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u));
     size_t lds_bytes = LDS ? (size_t)r->scene_words * 8 : 0;
@@ -414,7 +414,7 @@ __global__ void eu_wf_totals_kernel(EuWfBuffers B, uint32_t *__restrict__ out) {
 
 /* the FINISH step: the stream kernel takes over the queue of generation `gen` and everything below it */
 template <int D, int HSCAP, bool LDS>
-static int wf_launch_finish(eu_renderer *r, hipStream_t stream, int set, uint32_t gen, const EuDevCamera &dc, const EuDevFrame &df, const EuWfBuffers &B, uint32_t *rgba, double *point) {
+static int wf_launch_finish(eu_renderer *r, hipStream_t stream, int set, uint32_t gen, const EuDevCamera &dc, const EuDevFrame &df, const EuWfBuffers &B, uint32_t *rgba, eu_f64 *point) {
     auto kern = eu_ts_kernel<D, HSCAP, LDS>;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t hs_bytes = HSCAP == 0 ? (size_t)(EU_TS_BLOCK / 64) * hs_cap * 64 * 12 : 0;
@@ -442,7 +442,7 @@ static int wf_launch_finish(eu_renderer *r, hipStream_t stream, int set, uint32_
 }
 
 template <int D>
-static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
+static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
     /* Large frames are traced in bands of whole 8-row tiles so that the queue and node buffers stay bounded
      * (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes). */
     uint32_t band_rows = df_in.local_rows;
@@ -577,7 +577,7 @@ static int ts_ensure(eu_renderer *r, unsigned grid, uint32_t nch, size_t node_ch
 }
 
 template <int D, int HSCAP, bool LDS>
-static int ts_launch(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, double *hit_t, double *point) {
+static int ts_launch(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
     auto kern = eu_ts_kernel<D, HSCAP, LDS>;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     const size_t hs_bytes = HSCAP == 0 ? (size_t)(EU_TS_BLOCK / 64) * hs_cap * 64 * 12 : 0;
@@ -611,7 +611,7 @@ static int ts_launch(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, 
 }
 
 template <int D>
-static int ts_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, double *hit_t, double *point) {
+static int ts_launch_frame(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
     EuDevFrame df = df_in;
     df.band_row0 = 0; df.band_rows = df.local_rows; df.root_base = 0;
     const bool hs_lds = r->hit_cap <= 32;      /* else: private (scratch) hit stack */
@@ -629,7 +629,7 @@ static void ts_sum_rows(const unsigned long long *rows, unsigned n, eu_stats *ou
     *overflow = v[4];
 }
 
-static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_frame *f, hipStream_t stream, uint32_t *rgba, double *hit_t, double *point,
+static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_frame *f, hipStream_t stream, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point,
                               bool single = false, uint32_t single_x = 0) {
     if (!r || !cam || !f || !rgba) return EU_ERR_INVALID_ARGUMENT;
     if (cam->dim != r->dim) { r->err = "camera dimension does not match the scene"; return EU_ERR_INVALID_ARGUMENT; }
@@ -651,7 +651,7 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     df.tiles_x = (f->width + 7) / 8;
     df.n_tiles = df.tiles_x * ((rows + 7) / 8);
     df.debug_crosshair = f->debug_crosshair ? 1u : 0u;
-    df.time_s = (double)f->time_ms / 1000.0;
+    df.time_s = (double)f->time_ms / R(1000.0);
     if (single) { df.strip_count = 0; df.local_rows = 1; df.single_pixel = 1; df.single_x = single_x; df.single_y = f->row_begin; df.tiles_x = 1; df.n_tiles = 1; }
     if (rows == 0) return EU_OK;
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, sizeof(EuDevCounters), stream));
@@ -696,7 +696,7 @@ extern "C" uint32_t eu_frame_local_rows(const eu_frame *f) {
     return mine * 8;                                              /* padded: rows past row_end are left untouched */
 }
 
-extern "C" int eu_render_device(eu_renderer *r, const eu_camera *cam, const eu_frame *f, void *hip_stream, void *rgba_dev, double *hit_t_dev) {
+extern "C" int eu_render_device(eu_renderer *r, const eu_camera *cam, const eu_frame *f, void *hip_stream, void *rgba_dev, eu_f64 *hit_t_dev) {
     return render_device_impl(r, cam, f, (hipStream_t)hip_stream, (uint32_t *)rgba_dev, hit_t_dev, nullptr);
 }
 
@@ -791,11 +791,11 @@ static int ensure_buffers(eu_renderer *r, size_t pixels, bool want_hit) {
         HIP_TRY(hipMalloc((void **)&r->d_rgb, pixels * 3 + 16));
         r->rgba_pixels = pixels;
     }
-    if (want_hit && !r->d_hit) HIP_TRY(hipMalloc((void **)&r->d_hit, r->rgba_pixels * sizeof(double)));
+    if (want_hit && !r->d_hit) HIP_TRY(hipMalloc((void **)&r->d_hit, r->rgba_pixels * sizeof(eu_f64)));
     return EU_OK;
 }
 
-extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, double *hit_t_host, eu_stats *stats) {
+extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, eu_f64 *hit_t_host, eu_stats *stats) {
     if (!r || !cam || !f || !rgb_host) return EU_ERR_INVALID_ARGUMENT;
     if (f->row_begin > f->row_end || f->row_end > f->height) return EU_ERR_INVALID_ARGUMENT;
     const size_t pixels = (size_t)eu_frame_local_rows(f) * f->width;
@@ -812,7 +812,7 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
             eu_stats tmp;
             const int src = eu_renderer_stats(r, &tmp);
             if (src != EU_ERR_CAPACITY) break;
-            r->ts_node_factor = r->ts_node_factor * 2.0 > 2.0 ? r->ts_node_factor * 2.0 : 2.0;
+            r->ts_node_factor = r->ts_node_factor * R(2.0) > R(2.0) ? r->ts_node_factor * R(2.0) : R(2.0);
             rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
             if (rc != EU_OK) return rc;
         }
@@ -832,7 +832,7 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
     rc = eu_pack_rgb_device(r, r->d_rgba, r->d_rgb, pixels, nullptr);
     if (rc != EU_OK) return rc;
     HIP_TRY(hipMemcpy(rgb_host, r->d_rgb, pixels * 3, hipMemcpyDeviceToHost));
-    if (hit_t_host) HIP_TRY(hipMemcpy(hit_t_host, r->d_hit, pixels * sizeof(double), hipMemcpyDeviceToHost));
+    if (hit_t_host) HIP_TRY(hipMemcpy(hit_t_host, r->d_hit, pixels * sizeof(eu_f64), hipMemcpyDeviceToHost));
     if (stats) return eu_renderer_stats(r, stats);
     return EU_OK;
 }
@@ -847,7 +847,7 @@ extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const
     one.row_begin = (uint32_t)y; one.row_end = (uint32_t)y + 1;
     rc = render_device_impl(r, cam, &one, nullptr, r->d_rgba, nullptr, r->d_point, true, (uint32_t)x);
     if (rc != EU_OK) return rc;
-    HIP_TRY(hipMemcpy(rgb, r->d_point, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rgb, r->d_point, 3 * sizeof(eu_f64), hipMemcpyDeviceToHost));
     return EU_OK;
 }
 
@@ -1175,7 +1175,7 @@ extern "C" int eu_trace_path(eu_renderer *r, const double location[4], const dou
     HIP_TRY(hipGetLastError());
     EuPathResult res;
     HIP_TRY(hipMemcpy(&res, r->d_path_out, sizeof res, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; k++) { out_location[k] = k < D ? res.location[k] : 0.0; out_direction[k] = k < D ? res.direction[k] : 0.0; }
+    for (int k = 0; k < 4; k++) { out_location[k] = k < D ? res.location[k] : R(0.0); out_direction[k] = k < D ? res.direction[k] : R(0.0); }
     if (res.found < 0) { *found = 0; r->err = "trace_path: more than 4096 surface crossings"; return EU_ERR_PATH_STEPS; }
     *found = res.found;
     return EU_OK;

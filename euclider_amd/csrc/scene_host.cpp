@@ -157,7 +157,7 @@ ShapePtr Sphere_new(int dim, const double *center, double radius) {           /*
     return s;
 }
 ShapePtr Hyperplane_new(int dim, const double *normal, double constant) {     /* shape.rs:750-759 */
-    if (!(v_nsq(dim, normal) > 0.0)) fail(ParserError::CustomError, "Cannot have a normal with length of 0.");
+    if (!(v_nsq(dim, normal) > R(0.0))) fail(ParserError::CustomError, "Cannot have a normal with length of 0.");
     auto s = std::make_shared<Shape>(); s->kind = Shape::Hyperplane; s->dim = dim;
     for (int i = 0; i < dim; i++) s->a[i] = normal[i];
     s->r = constant;
@@ -201,9 +201,9 @@ ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op
 }
 static ShapePtr box_of_halfspaces(int D, const double *center, const double *abc) {
     double half[MAXD];
-    for (int i = 0; i < D; i++) half[i] = abc[i] / 2.0;
+    for (int i = 0; i < D; i++) half[i] = abc[i] / R(2.0);
     double axis[MAXD][MAXD] = {{0}};
-    for (int i = 0; i < D; i++) axis[i][i] = 1.0;
+    for (int i = 0; i < D; i++) axis[i][i] = R(1.0);
     std::vector<ShapePtr> shapes;
     for (int ax = 0; ax < D; ax++) for (int neg = 0; neg < 2; neg++) {
         double off[MAXD], pt[MAXD];
@@ -228,8 +228,8 @@ ShapePtr HalfSpace_cuboid(const double *center, const double *abc) { return box_
 ShapePtr HalfSpace_hypercuboid(const double *center, const double *abcd) { return box_of_halfspaces(4, center, abcd); }
 
 ShapePtr Cylinder_new(int dim, const double *center, const double *direction, double radius) {   /* shape.rs:893-904 */
-    if (!(v_nsq(dim, direction) > 0.0)) fail(ParserError::CustomError, "Cannot have a direction with length of 0.");
-    if (!(radius > 0.0)) fail(ParserError::CustomError, "The radius must be positive.");
+    if (!(v_nsq(dim, direction) > R(0.0))) fail(ParserError::CustomError, "Cannot have a direction with length of 0.");
+    if (!(radius > R(0.0))) fail(ParserError::CustomError, "The radius must be positive.");
     auto s = std::make_shared<Shape>(); s->kind = Shape::Cylinder; s->dim = dim;
     for (int i = 0; i < dim; i++) s->a[i] = center[i];
     v_normalize(dim, direction, s->b);
@@ -239,7 +239,7 @@ ShapePtr Cylinder_new(int dim, const double *center, const double *direction, do
 ShapePtr Cylinder_new_with_height(int dim, const double *center, const double *direction, double radius, double height) {   /* shape.rs:906-927 */
     double nd[MAXD], pt[MAXD];
     v_normalize(dim, direction, nd);
-    double half_height = height / (1.0 + 1.0);
+    double half_height = height / (R(1.0) + R(1.0));
     std::vector<ShapePtr> shapes;
     shapes.push_back(Cylinder_new(dim, center, direction, radius));
     for (int i = 0; i < dim; i++) pt[i] = center[i] + nd[i] * half_height;
@@ -256,9 +256,9 @@ eu_camera default_camera(int dim, const double *loc) {   /* d3/entity/camera.rs:
     memset(&c, 0, sizeof c);
     c.dim = dim;
     if (loc) for (int i = 0; i < dim; i++) c.location[i] = loc[i];
-    c.forward[0] = 1.0;
-    c.up[2] = 1.0;
-    c.left[1] = 1.0;
+    c.forward[0] = R(1.0);
+    c.up[2] = R(1.0);
+    c.left[1] = R(1.0);
     c.fov_deg = 90;
     c.max_depth = 10;
     return c;
@@ -267,21 +267,21 @@ eu_camera default_camera(int dim, const double *loc) {   /* d3/entity/camera.rs:
 /* palette 0.2.1 Hsv -> Rgb with RgbHue::to_positive_degrees (UNVERIFIED third-party semantics) */
 void rgba_from_hsva(double hue, double saturation, double value, double alpha, double *out) {
     double deg = hue;
-    if (fabs(deg) < 1.0e9) {
-        while (deg >= 360.0) deg = deg - 360.0;
-        while (deg < 0.0) deg = deg + 360.0;
+    if (fabs(deg) < R(1.0e9)) {
+        while (deg >= R(360.0)) deg = deg - R(360.0);
+        while (deg < R(0.0)) deg = deg + R(360.0);
     }
     double c = value * saturation;
-    double h = deg / 60.0;
-    double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
+    double h = deg / R(60.0);
+    double x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
     double m = value - c;
     double r, g, b;
-    if (h >= 0.0 && h < 1.0) { r = c; g = x; b = 0.0; }
-    else if (h >= 1.0 && h < 2.0) { r = x; g = c; b = 0.0; }
-    else if (h >= 2.0 && h < 3.0) { r = 0.0; g = c; b = x; }
-    else if (h >= 3.0 && h < 4.0) { r = 0.0; g = x; b = c; }
-    else if (h >= 4.0 && h < 5.0) { r = x; g = 0.0; b = c; }
-    else { r = c; g = 0.0; b = x; }
+    if (h >= R(0.0) && h < R(1.0)) { r = c; g = x; b = R(0.0); }
+    else if (h >= R(1.0) && h < R(2.0)) { r = x; g = c; b = R(0.0); }
+    else if (h >= R(2.0) && h < R(3.0)) { r = R(0.0); g = c; b = x; }
+    else if (h >= R(3.0) && h < R(4.0)) { r = R(0.0); g = x; b = c; }
+    else if (h >= R(4.0) && h < R(5.0)) { r = x; g = R(0.0); b = c; }
+    else { r = c; g = R(0.0); b = x; }
     out[0] = r + m; out[1] = g + m; out[2] = b + m; out[3] = alpha;
 }
 
@@ -309,7 +309,7 @@ const int FN_ARITY[EU_FN_COUNT] = {1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 2, 1};
 struct ExprCompiler {
     const std::string &s; size_t p = 0; std::vector<Expr::Tok> &out; bool ok = true;
     void ws() { while (p < s.size() && isspace((unsigned char)s[p])) p++; }
-    void emit(uint32_t op, uint32_t arg = 0, double k = 0.0, const std::string &v = "") { out.push_back({op, arg, k, v}); }
+    void emit(uint32_t op, uint32_t arg = 0, eu_f64 k = 0.0, const std::string &v = "") { out.push_back({op, arg, k, v}); }
     void atom() {
         ws();
         if (p >= s.size()) { ok = false; return; }
@@ -317,7 +317,7 @@ struct ExprCompiler {
         if (c == '(') { p++; expr(); ws(); if (p < s.size() && s[p] == ')') p++; else ok = false; return; }
         if (isdigit((unsigned char)c) || c == '.') {
             const char *b = s.c_str() + p; char *e = nullptr;
-            double v = strtod(b, &e);
+            eu_f64 v = strtod(b, &e);
             if (e == b) { ok = false; return; }
             p += (size_t)(e - b);
             emit(EU_RPN_CONST, 0, v);
@@ -340,7 +340,7 @@ struct ExprCompiler {
             }
             if (name == "pi") { emit(EU_RPN_CONST, 0, 3.14159265358979323846264338327950288); return; }
             if (name == "e") { emit(EU_RPN_CONST, 0, 2.71828182845904523536028747135266250); return; }
-            emit(EU_RPN_VAR, 0, 0.0, name);
+            emit(EU_RPN_VAR, 0, R(0.0), name);
             return;
         }
         ok = false;
@@ -415,7 +415,7 @@ static std::string ty_name(const Ty &x) {
     return s;
 }
 struct Value {
-    double num = 0.0;
+    double num = R(0.0);
     std::string str;
     std::array<double, 4> vec{{0, 0, 0, 0}};
     std::shared_ptr<void> obj;
@@ -482,8 +482,8 @@ struct Parser_ {
             Value v; v.num = j.num; return v;
         }
         case T::U8: case T::U32: {
-            double lim = type.t == T::U8 ? 255.0 : 4294967295.0;
-            if (j.type != Json::Number || !(j.num >= 0.0 && j.num <= lim) || j.num != floor(j.num))
+            double lim = type.t == T::U8 ? R(255.0) : R(4294967295.0);
+            if (j.type != Json::Number || !(j.num >= R(0.0) && j.num <= lim) || j.num != floor(j.num))
                 fail(ParserError::TypeMismatch, std::string("Expected `") + (type.t == T::U8 ? "8-bit unsigned integer" : "32-bit unsigned integer") + "`, could not parse from `" + j.brief() + "`.");
             Value v; v.num = j.num; return v;
         }
@@ -544,7 +544,7 @@ void Parser_::build_registry() {
     std::vector<Field> rgba_f = {{"r", ty(T::F)}, {"g", ty(T::F)}, {"b", ty(T::F)}, {"a", ty(T::F)}};
     add({"Rgba", "Rgba::new"}, rgba_f, ty(T::Rgba), [](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < 4; i++) v.vec[i] = a[i].num; return v; });
     add({"Rgba::new_u8"}, {{"r", ty(T::U8)}, {"g", ty(T::U8)}, {"b", ty(T::U8)}, {"a", ty(T::U8)}}, ty(T::Rgba),
-        [](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < 4; i++) v.vec[i] = a[i].num / 255.0; return v; });
+        [](Parser_ &, std::vector<Value> &a) { Value v; for (int i = 0; i < 4; i++) v.vec[i] = a[i].num / R(255.0); return v; });
     add({"Rgba::from_hsva"}, {{"hue", ty(T::F)}, {"saturation", ty(T::F)}, {"value", ty(T::F)}, {"alpha", ty(T::F)}}, ty(T::Rgba),
         [](Parser_ &, std::vector<Value> &a) { Value v; rgba_from_hsva(a[0].num, a[1].num, a[2].num, a[3].num, v.vec.data()); return v; });
     add({"SetOperation", "SetOperation::new"}, {{"name", ty(T::Str)}}, ty(T::SetOperation), [](Parser_ &, std::vector<Value> &a) {   /* scene.rs:774-787 */
@@ -736,10 +736,10 @@ struct Flattener {
             const Shape &l = *chain[k];
             if (l.kind != Shape::HalfSpace) return false;
             for (int i = 0; i < D; i++) {
-                if (i == k / 2) { if (!(l.a[i] == 1.0 || l.a[i] == -1.0)) return false; }
-                else if (!(l.a[i] == 0.0)) return false;
+                if (i == k / 2) { if (!(l.a[i] == R(1.0) || l.a[i] == -R(1.0))) return false; }
+                else if (!(l.a[i] == R(0.0))) return false;
             }
-            if (!std::isfinite(l.r) || l.r == 0.0) return false;
+            if (!std::isfinite(l.r) || l.r == R(0.0)) return false;
         }
         return true;
     }
@@ -775,13 +775,13 @@ struct Flattener {
             {   /* the chain's own bounding sphere (axis-aligned boxes only), right after its leaves: c[D], r2, far2; r2 < 0: none */
                 Bound b;
                 if (s.operation == SetOperation::Intersection) b = box_bound(chain);
-                double cmax = 0.0;
+                double cmax = R(0.0);
                 for (int i = 0; i < D; i++) cmax = std::max(cmax, fabs(b.c[i]));
-                const bool ok = b.ok && b.r > 0.0 && cmax <= 1.0e6 * b.r;
-                const double rr = b.r * (1.0 + 1.0e-6) + 1.0e-9 * std::max(1.0, cmax);
-                for (int i = 0; i < D; i++) params.push_back(ok ? b.c[i] : 0.0);
-                params.push_back(ok ? rr * rr : -1.0);
-                params.push_back(ok ? 1.0e8 * rr * rr : 0.0);
+                const bool ok = b.ok && b.r > R(0.0) && cmax <= R(1.0e6) * b.r;
+                const double rr = b.r * (R(1.0) + R(1.0e-6)) + R(1.0e-9) * std::max(R(1.0), cmax);
+                for (int i = 0; i < D; i++) params.push_back(ok ? b.c[i] : R(0.0));
+                params.push_back(ok ? rr * rr : -R(1.0));
+                params.push_back(ok ? R(1.0e8) * rr * rr : R(0.0));
             }
             n_leaves += (uint32_t)chain.size();
             len = (uint32_t)chain.size();
@@ -836,19 +836,19 @@ struct Flattener {
     }
 
     /* ---- conservative bounding spheres (exact culling, DESIGN.md "Culling") ---- */
-    struct Bound { bool ok = false; double c[MAXD] = {0, 0, 0, 0}; double r = 0.0; };
+    struct Bound { bool ok = false; double c[MAXD] = {0, 0, 0, 0}; double r = R(0.0); };
     std::vector<double> bounds;
 
     static Bound enclose(int D, const Bound &a, const Bound &b) {
         Bound o;
         if (!a.ok || !b.ok) return o;
-        double dist2 = 0.0;
+        double dist2 = R(0.0);
         for (int i = 0; i < D; i++) dist2 += (a.c[i] - b.c[i]) * (a.c[i] - b.c[i]);
         const double dist = sqrt(dist2);
         if (dist + b.r <= a.r) return a;
         if (dist + a.r <= b.r) return b;
         o.ok = true;
-        o.r = (dist + a.r + b.r) / 2.0;
+        o.r = (dist + a.r + b.r) / R(2.0);
         for (int i = 0; i < D; i++) o.c[i] = a.c[i] + (b.c[i] - a.c[i]) * ((o.r - a.r) / dist);
         return o;
     }
@@ -858,20 +858,20 @@ struct Flattener {
         Bound o;
         double lo[MAXD], hi[MAXD]; bool has_lo[MAXD] = {false, false, false, false}, has_hi[MAXD] = {false, false, false, false};
         for (auto *s : leaves) {
-            if (s->kind != Shape::HalfSpace || !(s->signum == 1.0 || s->signum == -1.0)) return o;
+            if (s->kind != Shape::HalfSpace || !(s->signum == R(1.0) || s->signum == -R(1.0))) return o;
             int axis = -1;
-            for (int i = 0; i < D; i++) if (s->a[i] != 0.0) { if (axis >= 0) return o; axis = i; }
+            for (int i = 0; i < D; i++) if (s->a[i] != R(0.0)) { if (axis >= 0) return o; axis = i; }
             if (axis < 0) return o;
             const double sn = s->a[axis], edge = -s->r / sn;          /* inside <=> sign(sn*x + c) == signum */
             if (!std::isfinite(edge)) return o;
-            if (s->signum * sn > 0.0) { if (!has_lo[axis] || edge > lo[axis]) lo[axis] = edge; has_lo[axis] = true; }
+            if (s->signum * sn > R(0.0)) { if (!has_lo[axis] || edge > lo[axis]) lo[axis] = edge; has_lo[axis] = true; }
             else { if (!has_hi[axis] || edge < hi[axis]) hi[axis] = edge; has_hi[axis] = true; }
         }
-        double r2 = 0.0;
+        double r2 = R(0.0);
         for (int i = 0; i < D; i++) {
             if (!has_lo[i] || !has_hi[i] || !(hi[i] >= lo[i])) return o;
-            o.c[i] = (lo[i] + hi[i]) / 2.0;
-            r2 += ((hi[i] - lo[i]) / 2.0) * ((hi[i] - lo[i]) / 2.0);
+            o.c[i] = (lo[i] + hi[i]) / R(2.0);
+            r2 += ((hi[i] - lo[i]) / R(2.0)) * ((hi[i] - lo[i]) / R(2.0));
         }
         o.r = sqrt(r2); o.ok = true;
         return o;
@@ -881,7 +881,7 @@ struct Flattener {
         Bound o;
         switch (s.kind) {
         case Shape::Sphere:
-            if (!(s.r > 0.0) || !std::isfinite(s.r)) return o;
+            if (!(s.r > R(0.0)) || !std::isfinite(s.r)) return o;
             o.ok = true; o.r = s.r;
             for (int i = 0; i < D; i++) o.c[i] = s.a[i];
             return o;
@@ -902,15 +902,15 @@ struct Flattener {
 
     uint32_t entity_bound(const Shape &s) {
         Bound b = shape_bound(s);
-        if (!b.ok || !(b.r > 0.0)) return 0xffffffffu;
-        double cmax = 0.0;
+        if (!b.ok || !(b.r > R(0.0))) return 0xffffffffu;
+        double cmax = R(0.0);
         for (int i = 0; i < D; i++) { if (!std::isfinite(b.c[i])) return 0xffffffffu; cmax = std::max(cmax, fabs(b.c[i])); }
-        if (cmax > 1.0e6 * b.r) return 0xffffffffu;          /* the margin below must dominate rounding of |o - c|^2 */
-        const double rr = b.r * (1.0 + 1.0e-6) + 1.0e-9 * std::max(1.0, cmax);
+        if (cmax > R(1.0e6) * b.r) return 0xffffffffu;          /* the margin below must dominate rounding of |o - c|^2 */
+        const double rr = b.r * (R(1.0) + R(1.0e-6)) + R(1.0e-9) * std::max(R(1.0), cmax);
         uint32_t id = (uint32_t)(bounds.size() / (size_t)(D + 2));
         for (int i = 0; i < D; i++) bounds.push_back(b.c[i]);
         bounds.push_back(rr * rr);
-        bounds.push_back(1.0e8 * rr * rr);
+        bounds.push_back(R(1.0e8) * rr * rr);
         return id;
     }
 
@@ -998,10 +998,10 @@ struct Flattener {
             op.fn = c.blend->fn; op.v[0] = c.blend->ratio;
             break;
         }
-        case EU_COL_UNIFORM: memcpy(op.c0, c.c0, sizeof op.c0); break;
-        case EU_COL_ILLUM_GLOBAL: memcpy(op.c0, c.c0, sizeof op.c0); memcpy(op.c1, c.c1, sizeof op.c1); break;
+        case EU_COL_UNIFORM: for (int i = 0; i < 4; i++) op.c0[i] = c.c0[i]; break;      /* (the flat records hold f64 whatever F is: element-wise, widening) */
+        case EU_COL_ILLUM_GLOBAL: for (int i = 0; i < 4; i++) { op.c0[i] = c.c0[i]; op.c1[i] = c.c1[i]; } break;
         case EU_COL_ILLUM_DIR:
-            memcpy(op.c0, c.c0, sizeof op.c0); memcpy(op.c1, c.c1, sizeof op.c1); memcpy(op.v, c.v, sizeof op.v);
+            for (int i = 0; i < 4; i++) { op.c0[i] = c.c0[i]; op.c1[i] = c.c1[i]; op.v[i] = c.v[i]; }
             for (int i = 0; i < D; i++) op.v[i] = -c.v[i];      /* surface.rs:403 uses -light_direction */
             break;
         case EU_COL_PERLIN: {
@@ -1025,7 +1025,7 @@ struct Flattener {
         EuFlatSurface fs{};
         fs.ratio_kind = s->reflection_ratio->kind; fs.ratio_p0 = s->reflection_ratio->p0; fs.ratio_p1 = s->reflection_ratio->p1;
         fs.thr_kind = s->threshold_direction->kind; fs.thr_p0 = s->threshold_direction->p0;
-        fs.thr_p0_inv = 1.0 / s->threshold_direction->p0;       /* surface.rs:278 */
+        fs.thr_p0_inv = R(1.0) / s->threshold_direction->p0;       /* surface.rs:278 */
         fs.color_first = (uint32_t)color_ops.size();
         uint32_t depth = emit_color(*s->surface_color);
         if (depth > color_depth) color_depth = depth;
@@ -1076,7 +1076,7 @@ FlatScene flatten(const Universe &u) {
         return off;
     };
     h.n_ops = (uint32_t)f.ops.size(); h.off_ops = append(f.ops.data(), f.ops.size() * sizeof(EuShapeOp));
-    h.n_params = (uint32_t)f.params.size(); h.off_params = append(f.params.data(), f.params.size() * 8);
+    h.n_params = (uint32_t)f.params.size(); h.off_params = append(f.params.data(), f.params.size() * sizeof(f.params[0]));
     h.n_entities = (uint32_t)f.entities.size(); h.off_entities = append(f.entities.data(), f.entities.size() * sizeof(EuFlatEntity));
     h.n_materials = (uint32_t)f.materials.size(); h.off_materials = append(f.materials.data(), f.materials.size() * sizeof(EuFlatMaterial));
     h.n_transforms = (uint32_t)(f.transforms.size() / 8); h.off_transforms = append(f.transforms.data(), f.transforms.size() * 8);
@@ -1085,12 +1085,12 @@ FlatScene flatten(const Universe &u) {
     h.n_color_ops = (uint32_t)f.color_ops.size(); h.off_color_ops = append(f.color_ops.data(), f.color_ops.size() * sizeof(EuFlatColorOp));
     h.n_mapped = (uint32_t)f.mapped.size(); h.off_mapped = append(f.mapped.data(), f.mapped.size() * sizeof(EuFlatMapped));
     h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
-    h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * 8);
+    h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * sizeof(f.bounds[0]));
     h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
     /* flags bit 0: some surface can spawn BOTH a transmission and a reflection ray (ratio strictly between 0 and 1
      * possible): the recursion tree branches and a frame holds several times more rays than pixels */
     for (auto &fs : f.surfaces)
-        if (fs.ratio_kind == EU_RATIO_FRESNEL || (fs.ratio_p0 > 0.0 && fs.ratio_p0 < 1.0)) h.flags |= 1u;
+        if (fs.ratio_kind == EU_RATIO_FRESNEL || (fs.ratio_p0 > R(0.0) && fs.ratio_p0 < R(1.0))) h.flags |= 1u;
     h.n_words = (uint32_t)w.size();
     memcpy(w.data(), &h, sizeof h);
     out.textures = f.textures;

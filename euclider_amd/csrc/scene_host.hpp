@@ -10,17 +10,26 @@
 #ifndef EU_SCENE_HOST_HPP
 #define EU_SCENE_HOST_HPP
 
+/* every system header the loader's translation units use comes first: eu_real.h (last include below) may redefine `double` */
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/euclider_amd.h"
 #include "flat_scene.h"
+#include "eu_math.h"
+#include "eu_real.h"
 
 namespace euclider {
 
@@ -39,7 +48,7 @@ struct ParserError {
 struct Json {
     enum Type { Null, Bool, Number, String, Array, Object } type = Null;
     bool b = false;
-    double num = 0.0;
+    eu_f64 num = R(0.0);        /* JSON numbers are f64 (json 0.11); a field of type F narrows it */
     std::string str;
     std::vector<Json> arr;
     std::vector<std::pair<std::string, Json>> obj;
@@ -56,8 +65,8 @@ struct Shape {
     int dim = 3;
     double a[MAXD] = {0, 0, 0, 0};   /* sphere centre | plane normal | cylinder centre */
     double b[MAXD] = {0, 0, 0, 0};   /* cylinder axis (normalised) */
-    double r = 0.0;                  /* radius | plane constant */
-    double signum = 0.0;             /* HalfSpace */
+    double r = R(0.0);                  /* radius | plane constant */
+    double signum = R(0.0);             /* HalfSpace */
     SetOperation operation = SetOperation::Union;
     std::shared_ptr<Shape> sa, sb;
 };
@@ -80,7 +89,7 @@ ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op
 /* meval-subset expression compiled to RPN words (flat_scene.h EuRpn) */
 struct Expr {
     std::string source;
-    struct Tok { uint32_t op, arg; double k; std::string var; };
+    struct Tok { uint32_t op, arg; eu_f64 k; std::string var; };      /* constants of an expression are f64 (meval) */
     std::vector<Tok> rpn;
     static Expr from_str(const std::string &s);     /* throws ParserError{CustomError} */
     int stack_depth() const;
@@ -100,7 +109,7 @@ struct Texture { uint32_t kind = 0, w = 0, h = 0; std::shared_ptr<std::vector<ui
 struct UVFn { int dim = 3; double center[3] = {0, 0, 0}; };   /* uv_sphere_3, optionally wrapped by uv_derank_4 */
 struct MappedTexture { int dim = 3; std::shared_ptr<UVFn> uvfn; std::shared_ptr<Texture> texture; };
 
-struct BlendFunction { uint32_t fn = 0; double ratio = 0.0; };
+struct BlendFunction { uint32_t fn = 0; double ratio = R(0.0); };
 struct SurfaceColor {
     uint32_t kind = 0;                 /* EuColorKind */
     int dim = 3;

@@ -28,13 +28,14 @@
 
 #include "eu_math.h"
 #include "flat_scene.h"
+#include "eu_real.h"      /* after the headers whose doubles stay doubles: the elementary functions and the flat record structs */
 
 #define EU_DEV __device__ __forceinline__
 #define EU_RPN_INLINE __device__ __noinline__
 #define EU_MAX_DEPTH 16
-#define EU_PI_C 3.14159265358979323846264338327950288
-#define EU_FRAC_PI_2_C 1.57079632679489661923132169163975144
-#define EU_EPS 1.0e-6 /* nalgebra 0.8.2 approx_epsilon (UNVERIFIED), surface.rs:84,133 */
+#define EU_PI_C R(3.14159265358979323846264338327950288)
+#define EU_FRAC_PI_2_C R(1.57079632679489661923132169163975144)
+#define EU_EPS R(1.0e-6) /* nalgebra 0.8.2 approx_epsilon (UNVERIFIED), surface.rs:84,133 */
 
 struct EuDevCamera {
     double location[4], forward[4], up[4], right[4];
@@ -76,12 +77,12 @@ struct EuScene {
         off_perlin = h->off_perlin; background = h->background; off_bounds = h->off_bounds;
     }
     EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
-    EU_DEV double dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
+    EU_DEV eu_f64 dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
     EU_DEV void op(uint32_t i, uint32_t &kind, uint32_t &first, uint32_t &param, uint32_t &count) const {
         uint64_t x = w[off_ops + i];
         kind = (uint32_t)(x & 0xff); count = (uint32_t)((x >> 8) & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
     }
-    EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params + off); }
+    EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params) + off; }      /* offsets count elements of F */
     /* EuFlatEntity by value, unpacked from two 64-bit words: there are no sub-dword scalar loads, a 16-bit field read through
      * a pointer becomes a VECTOR load followed by s_waitcnt vmcnt(0) -- a full memory drain per entity of the intersect loop */
     struct EntityView { uint32_t shape_first, shape_root, material; int32_t surface; uint32_t max_hits, bound; };
@@ -94,7 +95,7 @@ struct EuScene {
     EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
     EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
     EU_DEV uint64_t texels(uint32_t m) const { return ((const EuFlatMapped *)(wrt + off_mapped + 8 * m))->texels; }
-    EU_DEV const double *bounds(uint32_t b, int D) const { return (const double *)(w + off_bounds + (uint32_t)(D + 2) * b); }
+    EU_DEV const double *bounds(uint32_t b, int D) const { return (const double *)(w + off_bounds) + (uint32_t)(D + 2) * b; }
     EU_DEV const uint8_t *perlin(uint32_t p) const { return (const uint8_t *)(w + off_perlin + 64 * p); }
 };
 
@@ -114,17 +115,21 @@ template <int D> EU_DEV void vnormalize(const double *a, double *o) {
 }
 template <int D> EU_DEV double angle_between(const double *a, const double *b) {   /* util.rs:712-722 */
     double r = eu_acos(vdot<D>(a, b) / (vnorm<D>(a) * vnorm<D>(b)));
-    return (r != r) ? 0.0 : r;
+    return (r != r) ? R(0.0) : r;
 }
-EU_DEV double rust_signum(double x) { if (x != x) return x; return (eu_hi(x) >> 31) ? -1.0 : 1.0; }
+EU_DEV double rust_signum(double x) { if (x != x) return x; return (eu_hi((eu_f64)x) >> 31) ? -R(1.0) : R(1.0); }      /* (widening keeps the sign, of zeros too) */
 EU_DEV double rust_min(double a, double b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
 EU_DEV double rust_max(double a, double b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
-EU_DEV double clamp01(double v) { if (v < 0.0) return 0.0; if (v > 1.0) return 1.0; return v; }
+EU_DEV double clamp01(double v) { if (v < R(0.0)) return R(0.0); if (v > R(1.0)) return R(1.0); return v; }
+#if EU_REAL_BITS == 32
+EU_DEV bool is_normal_f64(double x) { uint32_t e = (__float_as_uint(x) >> 23) & 0xffu; return e != 0 && e != 0xffu; }      /* f32::is_normal */
+#else
 EU_DEV bool is_normal_f64(double x) { uint32_t e = (eu_hi(x) >> 20) & 0x7ff; return e != 0 && e != 0x7ff; }
+#endif
 EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
     double rem = fmod(a, b);
-    if (rem == 0.0) return 0.0;
-    if (a < 0.0) return b + rem;
+    if (rem == R(0.0)) return R(0.0);
+    if (a < R(0.0)) return b + rem;
     return rem;
 }
 
@@ -133,35 +138,35 @@ EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
 struct LeafHits { int n; double t0, t1; };      /* returned by value: reference out-parameters ended up in scratch memory */
 
 EU_DEV LeafHits quad_roots(double a, double b, double c) {
-    LeafHits r = {0, 0.0, 0.0};
-    double d = b * b - 4.0 * a * c;
-    if (d < 0.0) return r;
+    LeafHits r = {0, R(0.0), R(0.0)};
+    double d = b * b - R(4.0) * a * c;
+    if (d < R(0.0)) return r;
     double d_sqrt = sqrt(d);
-    double t1 = (-b - d_sqrt) / (2.0 * a);
-    double t2 = (-b + d_sqrt) / (2.0 * a);
-    if (t1 >= 0.0) {
+    double t1 = (-b - d_sqrt) / (R(2.0) * a);
+    double t2 = (-b + d_sqrt) / (R(2.0) * a);
+    if (t1 >= R(0.0)) {
         r.t0 = t1; r.n = 1;
-        if (t2 >= 0.0) { r.t1 = t2; r.n = 2; }
-    } else if (t2 >= 0.0) { r.t0 = t2; r.n = 1; }
+        if (t2 >= R(0.0)) { r.t1 = t2; r.n = 2; }
+    } else if (t2 >= R(0.0)) { r.t0 = t2; r.n = 1; }
     return r;
 }
 
 template <int D> EU_DEV LeafHits leaf_hits(uint32_t kind, const double *P, const double *o, const double *d) {
-    LeafHits none = {0, 0.0, 0.0};
+    LeafHits none = {0, R(0.0), R(0.0)};
     switch (kind) {
     case EU_SH_SPHERE: {                                  /* shape.rs:652-731 */
         double rel[D];
 #pragma unroll
         for (int i = 0; i < D; i++) rel[i] = o[i] - P[i];
         double a = vnsq<D>(d);
-        double b = 2.0 * vdot<D>(d, rel);
+        double b = R(2.0) * vdot<D>(d, rel);
         double c = vnsq<D>(rel) - P[D + 1];
         return quad_roots(a, b, c);
     }
     case EU_SH_PLANE: case EU_SH_HALFSPACE: {             /* shape.rs:779-809, 843-870 */
         double t = -(vdot<D>(P, o) + P[D]) / vdot<D>(P, d);
-        if (t < 0.0) return none;
-        LeafHits r = {1, t, 0.0};
+        if (t < R(0.0)) return none;
+        LeafHits r = {1, t, R(0.0)};
         return r;
     }
     case EU_SH_CYLINDER: {                                /* shape.rs:935-1027 */
@@ -176,7 +181,7 @@ template <int D> EU_DEV LeafHits leaf_hits(uint32_t kind, const double *P, const
 #pragma unroll
         for (int i = 0; i < D; i++) c_vec[i] = delta[i] - ax[i] * k2;
         double a = vnsq<D>(a_vec);
-        double b = (1.0 + 1.0) * vdot<D>(a_vec, c_vec);
+        double b = (R(1.0) + R(1.0)) * vdot<D>(a_vec, c_vec);
         double c = vnsq<D>(c_vec) - P[2 * D + 1];
         return quad_roots(a, b, c);
     }
@@ -341,12 +346,12 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
     uint32_t pres = 0;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
-        tk[k] = 0.0;
+        tk[k] = R(0.0);
         if (k < n) {
             const double *Pk = P + k * EU_HS_STRIDE(D);
             const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
             tk[k] = t;
-            if (!(t < 0.0)) pres |= 1u << k;
+            if (!(t < R(0.0))) pres |= 1u << k;
         }
     }
     /* in_k[j] bit i: leaf j contains hit i ; lt_k[j] bit i: t_i < t_j */
@@ -386,7 +391,7 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
 template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
     bool ok = true;
 #pragma unroll
-    for (int m = 0; m < D; m++) ok = ok && __builtin_isfinite(o[m]) && __builtin_isfinite(d[m]) && d[m] != 0.0;
+    for (int m = 0; m < D; m++) ok = ok && __builtin_isfinite(o[m]) && __builtin_isfinite(d[m]) && d[m] != R(0.0);
     return ok;
 }
 
@@ -398,12 +403,12 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
     uint32_t pres = 0;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
-        tk[k] = 0.0;
+        tk[k] = R(0.0);
         if (k < n) {
             const double *Pk = P + k * EU_HS_STRIDE(D);
             const double t = -(Pk[k / 2] * o[k / 2] + Pk[D]) / (Pk[k / 2] * d[k / 2]);
             tk[k] = t;
-            if (!(t < 0.0)) pres |= 1u << k;
+            if (!(t < R(0.0))) pres |= 1u << k;
         }
     }
 #pragma unroll
@@ -492,16 +497,16 @@ EU_DEV int union_chain_first(uint32_t n, const double *P, const double *o, const
     bool has_nan = false;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
-        tk[k] = 0.0;
+        tk[k] = R(0.0);
         if (k < n) {
             const double *Pk = P + k * EU_HS_STRIDE(D);
             const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
             tk[k] = t;
-            if (!(t < 0.0)) { pres |= 1u << k; if (t != t) has_nan = true; }
+            if (!(t < R(0.0))) { pres |= 1u << k; if (t != t) has_nan = true; }
         }
     }
     if (pres == 0) return 0;
-    double best = 0.0; uint32_t idx = 0; bool have = false;
+    double best = R(0.0); uint32_t idx = 0; bool have = false;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         if (k < n && ((pres >> k) & 1u) && (!have || tk[k] < best)) { best = tk[k]; idx = k; have = true; }
@@ -542,12 +547,12 @@ template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o,
     for (int i = 0; i < D; i++) rel[i] = o[i] - Bd[i];
     const double rr = vdot<D>(rel, rel);
     const double cc = rr - Bd[D];
-    if (cc > 0.0) {                                   /* origin outside the enlarged sphere */
+    if (cc > R(0.0)) {                                   /* origin outside the enlarged sphere */
         const double b = vdot<D>(d, rel);
-        if (b >= 0.0) return true;                    /* moving away: the closest point is the origin */
+        if (b >= R(0.0)) return true;                    /* moving away: the closest point is the origin */
         if (rr < Bd[D + 1]) {                         /* discriminant margin only holds for |o-c| < 1e4 R */
             const double a = vdot<D>(d, d);
-            if (b * b - a * cc < 0.0) return true;    /* the whole line misses */
+            if (b * b - a * cc < R(0.0)) return true;    /* the whole line misses */
         }
     }
     return false;
@@ -566,9 +571,9 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             double tk[EU_CHAIN_MAX]; uint32_t list;
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
-            if (Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)) return 0u;
+            if (Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)) return 0u;
             if (kind == EU_SH_CHAIN_UNION) {
-                double tf = 0.0; uint32_t idx = 0;
+                double tf = R(0.0); uint32_t idx = 0;
                 const int q = union_chain_first<D>(count, Pc, o, d, tf, idx);
                 if (q == 0) return 0u;
                 if (q > 0) { first_t = tf; first_c = root | (idx << 16); return 1u; }
@@ -601,7 +606,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
             if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
-            else if (!(Pb[D] >= 0.0 && ray_misses_bound<D>(Pb, o, d)))
+            else if (!(Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)))
                 n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
             if (n) {
 #pragma unroll
@@ -647,7 +652,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if ((!sa && unk_a) || (!sb && unk_b)) { out_unk = true; break; }      /* next() asks both children first (shape.rs:214-215 ...) */
             if (!sa && !sb) break;
             if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
-            double ta = 0.0, tb = 0.0; uint32_t ca = 0, cb = 0;
+            double ta = R(0.0), tb = R(0.0); uint32_t ca = 0, cb = 0;
             if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
             if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
             const bool both = sa && sb;
@@ -763,39 +768,44 @@ template <int D> EU_DEV int material_at(const EuScene &S, const double *p) {
 }
 
 /* ------------------------------------------------------------------ materials */
-EU_DEV double pow_int(double x, double y) {   /* meval powf restricted to integral |y| <= 64 (documented deviation) */
+/* LinearSpace expressions: meval evaluates in f64 whatever F is and the result is cast to F (material.rs:99-111), so these
+ * routines are eu_f64 throughout */
+EU_DEV eu_f64 rpn_min(eu_f64 a, eu_f64 b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
+EU_DEV eu_f64 rpn_max(eu_f64 a, eu_f64 b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
+EU_DEV eu_f64 rpn_signum(eu_f64 x) { if (x != x) return x; return (eu_hi(x) >> 31) ? -1.0 : 1.0; }
+EU_DEV eu_f64 pow_int(eu_f64 x, eu_f64 y) {   /* meval powf restricted to integral |y| <= 64 (documented deviation) */
     if (!(y == floor(y)) || fabs(y) > 64.0) return __longlong_as_double(0x7ff8000000000000ll);
     int n = (int)fabs(y);
-    double r = 1.0;
+    eu_f64 r = 1.0;
     for (int i = 0; i < n; i++) r = r * x;
     return (y < 0.0) ? 1.0 / r : r;
 }
 
-template <int D> EU_RPN_INLINE double eval_rpn(const EuScene &S, uint64_t prog, const double *ctx) {
+template <int D> EU_RPN_INLINE eu_f64 eval_rpn(const EuScene &S, uint64_t prog, const eu_f64 *ctx) {
     uint32_t off = (uint32_t)prog, len = (uint32_t)(prog >> 32);
-    double st[8];
+    eu_f64 st[8];
     int sp = 0;
     for (uint32_t i = 0; i < len; i++) {
         uint64_t wd = S.word(S.off_code + off + i);
         uint32_t op = (uint32_t)wd, arg = (uint32_t)(wd >> 32);
         switch (op) {
         case EU_RPN_CONST: i++; st[sp++ & 7] = S.dbl(S.off_code + off + i); break;
-        case EU_RPN_VAR: { double v = ctx[0];
+        case EU_RPN_VAR: { eu_f64 v = ctx[0];
 #pragma unroll
             for (int k = 1; k < D; k++) if ((int)arg == k) v = ctx[k];
             st[sp++ & 7] = v; break; }
         case EU_RPN_NEG: st[(sp - 1) & 7] = -st[(sp - 1) & 7]; break;
         case EU_RPN_FN: {
-            double y = st[(sp - 1) & 7], x = y;
+            eu_f64 y = st[(sp - 1) & 7], x = y;
             if (arg == EU_FN_MIN || arg == EU_FN_MAX || arg == EU_FN_ATAN2) { sp--; x = st[(sp - 1) & 7]; }
-            double r;
+            eu_f64 r;
             switch (arg) {
             case EU_FN_SQRT: r = sqrt(x); break;
             case EU_FN_ABS: r = fabs(x); break;
             case EU_FN_FLOOR: r = floor(x); break;
             case EU_FN_CEIL: r = ceil(x); break;
-            case EU_FN_MIN: r = rust_min(x, y); break;
-            case EU_FN_MAX: r = rust_max(x, y); break;
+            case EU_FN_MIN: r = rpn_min(x, y); break;
+            case EU_FN_MAX: r = rpn_max(x, y); break;
             case EU_FN_SIN: r = eu_sin(x); break;
             case EU_FN_COS: r = eu_cos(x); break;
             case EU_FN_TAN: r = eu_tan(x); break;
@@ -803,15 +813,15 @@ template <int D> EU_RPN_INLINE double eval_rpn(const EuScene &S, uint64_t prog, 
             case EU_FN_ACOS: r = eu_acos(x); break;
             case EU_FN_ATAN: r = eu_atan(x); break;
             case EU_FN_ATAN2: r = eu_atan2(x, y); break;
-            default: r = rust_signum(x); break;
+            default: r = rpn_signum(x); break;
             }
             st[(sp - 1) & 7] = r;
             break;
         }
         default: {
-            double y = st[(sp - 1) & 7]; sp--;
-            double x = st[(sp - 1) & 7];
-            double r;
+            eu_f64 y = st[(sp - 1) & 7]; sp--;
+            eu_f64 x = st[(sp - 1) & 7];
+            eu_f64 r;
             switch (op) {
             case EU_RPN_ADD: r = x + y; break;
             case EU_RPN_SUB: r = x - y; break;
@@ -836,11 +846,11 @@ template <int D> EU_DEV void material_apply(const EuScene &S, uint32_t material,
     if (kind != EU_MAT_LINEAR) return;
     for (uint32_t k = 0; k < ntr; k++) {
         uint32_t tr = exit_ ? (first + ntr - 1 - k) : (first + k);
-        double ctx[D];
+        eu_f64 ctx[D];
 #pragma unroll
         for (int i = 0; i < D; i++) ctx[i] = dir[i];
 #pragma unroll
-        for (int i = 0; i < D; i++) dir[i] = eval_rpn<D>(S, S.word(S.off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i), ctx);
+        for (int i = 0; i < D; i++) dir[i] = (double)eval_rpn<D>(S, S.word(S.off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i), ctx);
     }
 }
 
@@ -850,12 +860,12 @@ EU_DEV Rgba from_premultiplied(Rgba p) {
     double a = clamp01(p.a);
     Rgba c;
     if (is_normal_f64(a)) { c.r = p.r / a; c.g = p.g / a; c.b = p.b / a; }
-    else { c.r = 0.0; c.g = 0.0; c.b = 0.0; }
+    else { c.r = R(0.0); c.g = R(0.0); c.b = R(0.0); }
     c.a = a;
     return c;
 }
 __device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, double sa, double da) {
-    const double one = 1.0, two = 2.0;
+    const double one = R(1.0), two = R(2.0);
     switch (fn) {
     case EU_BL_OVER: return a + b * (one - sa);
     case EU_BL_INSIDE: return a * da;
@@ -882,11 +892,11 @@ __device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, doubl
         if (a * two <= sa) return two * a * b + a * (one - da) + b * (one - sa);
         return a * (one + da) + b * (one + sa) - two * a * b - sa * da;
     case EU_BL_SOFT_LIGHT: {
-        double m = is_normal_f64(da) ? b / da : 0.0;
+        double m = is_normal_f64(da) ? b / da : R(0.0);
         if (a * two <= sa) return b * (sa + (two * a - sa) * (one - m)) + a * (one - da) + b * (one - sa);
-        if (b * 4.0 <= da) {
+        if (b * R(4.0) <= da) {
             double m2 = m * m, m3 = m2 * m;
-            return da * (two * a - sa) * (m3 * 16.0 - m2 * 12.0 - m * 3.0) + a - a * da + b;
+            return da * (two * a - sa) * (m3 * R(16.0) - m2 * R(12.0) - m * R(3.0)) + a - a * da + b;
         }
         return da * (two * a - sa) * (sqrt(m) - m) + a - a * da + b;
     }
@@ -897,16 +907,16 @@ __device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, doubl
 EU_DEV double blend_alpha(uint32_t fn, double sa, double da) {
     switch (fn) {
     case EU_BL_INSIDE: return clamp01(sa * da);
-    case EU_BL_OUTSIDE: return clamp01(sa * (1.0 - da));
+    case EU_BL_OUTSIDE: return clamp01(sa * (R(1.0) - da));
     case EU_BL_ATOP: return clamp01(da);
-    case EU_BL_XOR: return clamp01(sa + da - 2.0 * sa * da);
+    case EU_BL_XOR: return clamp01(sa + da - R(2.0) * sa * da);
     case EU_BL_PLUS: return clamp01(sa + da);
     default: return clamp01(sa + da - sa * da);
     }
 }
 EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
     Rgba o;
-    const double one = 1.0, two = 2.0, sa = s.a, da = d.a;
+    const double one = R(1.0), two = R(2.0), sa = s.a, da = d.a;
     switch (fn) {      /* the modes the shipped scenes use are expanded in line; the rest go through blend_chan */
     case EU_BL_OVER:
         o.r = s.r + d.r * (one - sa); o.g = s.g + d.g * (one - sa); o.b = s.b + d.b * (one - sa);
@@ -932,12 +942,12 @@ EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
 }
 EU_DEV Rgba blend_rgba(uint32_t fn, Rgba s, Rgba d) { return from_premultiplied(blend_pre(fn, into_premultiplied(s), into_premultiplied(d))); }   /* surface.rs:315-322 */
 EU_DEV Rgba combine_palette_color(Rgba a, Rgba b, double r) {   /* util.rs:265-285 */
-    if (r <= 0.0) return b;
-    if (r >= 1.0) return a;
-    return Rgba{a.r * r + b.r * (1.0 - r), a.g * r + b.g * (1.0 - r), a.b * r + b.b * (1.0 - r), a.a * r + b.a * (1.0 - r)};
+    if (r <= R(0.0)) return b;
+    if (r >= R(1.0)) return a;
+    return Rgba{a.r * r + b.r * (R(1.0) - r), a.g * r + b.g * (R(1.0) - r), a.b * r + b.b * (R(1.0) - r), a.a * r + b.a * (R(1.0) - r)};
 }
 EU_DEV uint32_t to_u8(double c, LaneCounters &cnt) {
-    double v = clamp01(c) * 255.0;
+    double v = clamp01(c) * R(255.0);
     if (v != v) { cnt.nan_px++; return 0; }
     return (uint32_t)v;
 }
@@ -945,31 +955,31 @@ EU_DEV uint32_t to_pixel4(Rgba c, LaneCounters &cnt) {
     return to_u8(c.r, cnt) | (to_u8(c.g, cnt) << 8) | (to_u8(c.b, cnt) << 16) | (to_u8(c.a, cnt) << 24);
 }
 EU_DEV Rgba new_u8(uint32_t px) {
-    return Rgba{(double)(px & 0xff) / 255.0, (double)((px >> 8) & 0xff) / 255.0, (double)((px >> 16) & 0xff) / 255.0, (double)(px >> 24) / 255.0};
+    return Rgba{(double)(px & 0xff) / R(255.0), (double)((px >> 8) & 0xff) / R(255.0), (double)((px >> 16) & 0xff) / R(255.0), (double)(px >> 24) / R(255.0)};
 }
 EU_DEV void hsv_to_rgb(double hue, double saturation, double value, double &r, double &g, double &b) {
     double deg = hue;
-    if (fabs(deg) < 1.0e9) {
-        while (deg >= 360.0) deg = deg - 360.0;
-        while (deg < 0.0) deg = deg + 360.0;
+    if (fabs(deg) < R(1.0e9)) {
+        while (deg >= R(360.0)) deg = deg - R(360.0);
+        while (deg < R(0.0)) deg = deg + R(360.0);
     }
     double c = value * saturation;
-    double h = deg / 60.0;
-    double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
+    double h = deg / R(60.0);
+    double x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
     double m = value - c;
     double red, green, blue;
-    if (h >= 0.0 && h < 1.0) { red = c; green = x; blue = 0.0; }
-    else if (h >= 1.0 && h < 2.0) { red = x; green = c; blue = 0.0; }
-    else if (h >= 2.0 && h < 3.0) { red = 0.0; green = c; blue = x; }
-    else if (h >= 3.0 && h < 4.0) { red = 0.0; green = x; blue = c; }
-    else if (h >= 4.0 && h < 5.0) { red = x; green = 0.0; blue = c; }
-    else { red = c; green = 0.0; blue = x; }
+    if (h >= R(0.0) && h < R(1.0)) { red = c; green = x; blue = R(0.0); }
+    else if (h >= R(1.0) && h < R(2.0)) { red = x; green = c; blue = R(0.0); }
+    else if (h >= R(2.0) && h < R(3.0)) { red = R(0.0); green = c; blue = x; }
+    else if (h >= R(3.0) && h < R(4.0)) { red = R(0.0); green = x; blue = c; }
+    else if (h >= R(4.0) && h < R(5.0)) { red = x; green = R(0.0); blue = c; }
+    else { red = c; green = R(0.0); blue = x; }
     r = red + m; g = green + m; b = blue + m;
 }
 
 /* ------------------------------------------------------------------ own 4-D gradient noise (documented substitute
  * for noise 0.4.1 Perlin + rand::random() seed, d3/entity/surface.rs:22-58) */
-EU_DEV double pfade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+EU_DEV double pfade(double t) { return t * t * t * (t * (t * R(6.0) - R(15.0)) + R(10.0)); }
 EU_DEV double plerp(double t, double a, double b) { return a + t * (b - a); }
 EU_DEV double pgrad4(int hash, double x, double y, double z, double w) {
     int h = hash & 31;
@@ -978,7 +988,7 @@ EU_DEV double pgrad4(int hash, double x, double y, double z, double w) {
     double c = (h < 8) ? z : w;
     return ((h & 1) ? -a : a) + ((h & 2) ? -b : b) + ((h & 4) ? -c : c);
 }
-EU_DEV int pcell(double f) { double m = fmod(f, 256.0); return (m == m) ? (((int)m) & 255) : 0; }
+EU_DEV int pcell(double f) { double m = fmod(f, R(256.0)); return (m == m) ? (((int)m) & 255) : 0; }
 __device__ __noinline__ double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
     double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
     int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
@@ -1001,12 +1011,12 @@ __device__ __noinline__ double perlin4(const uint8_t *perm, double x, double y, 
         }
         lw[dw] = plerp(s, lz[0], lz[1]);
     }
-    return 0.87 * plerp(q, lw[0], lw[1]);
+    return R(0.87) * plerp(q, lw[0], lw[1]);
 }
 
 /* ------------------------------------------------------------------ textures */
 EU_DEV bool cast_u32(double x, uint32_t &out, LaneCounters &cnt) {   /* NumCast: None (panic) when NaN / out of range */
-    if (!(x > -1.0 && x < 4294967296.0)) { cnt.errors++; out = 0; return false; }
+    if (!(x > -R(1.0) && x < R(4294967296.0))) { cnt.errors++; out = 0; return false; }
     out = (uint32_t)x;
     return true;
 }
@@ -1018,8 +1028,8 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
 #pragma unroll
     for (int i = 0; i < 3; i++) p[i] = point[i] - M->center[i];
     vnormalize<3>(p, pn);
-    double pu = 0.5 + eu_atan2(pn[1], pn[0]) / (2.0 * EU_PI_C);
-    double pv = 0.5 - eu_asin(pn[2]) / EU_PI_C;
+    double pu = R(0.5) + eu_atan2(pn[1], pn[0]) / (R(2.0) * EU_PI_C);
+    double pv = R(0.5) - eu_asin(pn[2]) / EU_PI_C;
     const uint32_t W = M->w, H = M->h;
     /* texels live in device (global) memory; the address comes out of the scene blob, so say so: a generic pointer would be
      * read with flat loads (vmcnt and lgkmcnt both) */
@@ -1032,15 +1042,15 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
         xi = xi % W; yi = yi % H;
         return new_u8(tex[(size_t)yi * W + xi]);
     }
-    double x = pu * M->wd - 0.5, y = pv * M->hd - 0.5;        /* surface.rs:453-489 */
+    double x = pu * M->wd - R(0.5), y = pv * M->hd - R(0.5);        /* surface.rs:453-489 */
     double ox = x - floor(x), oy = y - floor(y);
     uint32_t x0, x1, y0, y1;
     /* the reference casts x and y once per texel (4 texels, surface.rs:462-472); each coordinate
      * serves two texels, so a failed cast counts twice */
-    if (!cast_u32(remainder_f(x + 0.0, M->wd), x0, cnt)) cnt.errors++;
-    if (!cast_u32(remainder_f(x + 1.0, M->wd), x1, cnt)) cnt.errors++;
-    if (!cast_u32(remainder_f(y + 0.0, M->hd), y0, cnt)) cnt.errors++;
-    if (!cast_u32(remainder_f(y + 1.0, M->hd), y1, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(x + R(0.0), M->wd), x0, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(x + R(1.0), M->wd), x1, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(y + R(0.0), M->hd), y0, cnt)) cnt.errors++;
+    if (!cast_u32(remainder_f(y + R(1.0), M->hd), y1, cnt)) cnt.errors++;
     if (x0 >= W) { cnt.errors++; x0 = W - 1; }
     if (x1 >= W) { cnt.errors++; x1 = W - 1; }
     if (y0 >= H) { cnt.errors++; y0 = H - 1; }
@@ -1052,7 +1062,7 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
     for (int k = 0; k < 4; k++) {
         double c0 = (double)((p0 >> (8 * k)) & 0xff), c1 = (double)((p1 >> (8 * k)) & 0xff);
         double c2 = (double)((p2 >> (8 * k)) & 0xff), c3 = (double)((p3 >> (8 * k)) & 0xff);
-        ch[k] = ((c0 * (1.0 - ox) + c1 * ox) * (1.0 - oy) + (c2 * (1.0 - ox) + c3 * ox) * oy) / 255.0;
+        ch[k] = ((c0 * (R(1.0) - ox) + c1 * ox) * (R(1.0) - oy) + (c2 * (R(1.0) - ox) + c3 * ox) * oy) / R(255.0);
     }
     return Rgba{ch[0], ch[1], ch[2], ch[3]};
 }
@@ -1083,14 +1093,14 @@ template <int D> struct HitCtx {
     EU_DEV void classify() {    /* universe/mod.rs:118-125 */
         x_e = vdot<D>(dir, normal) / (vnorm<D>(dir) * vnorm<D>(normal));
         const double r = eu_acos(x_e);
-        ang_e = (r != r) ? 0.0 : r;
+        ang_e = (r != r) ? R(0.0) : r;
         have_me = false; have_sin = false; have_to = false;
         exiting = ang_e < EU_FRAC_PI_2_C;
 #pragma unroll
         for (int k = 0; k < D; k++) nc[k] = exiting ? -normal[k] : normal[k];
     }
     EU_DEV double angle_neg() {
-        if (!have_me) { const double r = eu_acos(-x_e); ang_me = (r != r) ? 0.0 : r; have_me = true; }
+        if (!have_me) { const double r = eu_acos(-x_e); ang_me = (r != r) ? R(0.0) : r; have_me = true; }
         return ang_me;
     }
     EU_DEV double angle_dir_nc() { return exiting ? angle_neg() : ang_e; }          /* angle_between(nc, dir) */
@@ -1107,12 +1117,12 @@ template <int D> struct HitCtx {
 };
 
 template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, HitCtx<D> &c) {
-    if (F->ratio_kind == EU_RATIO_UNIFORM) return c.exiting ? 0.0 : F->ratio_p0;     /* surface.rs:200-211 */
+    if (F->ratio_kind == EU_RATIO_UNIFORM) return c.exiting ? R(0.0) : F->ratio_p0;     /* surface.rs:200-211 */
     const double from_theta = c.angle_dir_minus_nc();                                 /* surface.rs:213-244 */
     const double from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
     const double to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
     const double to_theta = c.to_theta_for(from_index / to_index);
-    if (to_theta != to_theta) return 1.0;
+    if (to_theta != to_theta) return R(1.0);
     const double cos_from = eu_cos(from_theta), cos_to = eu_cos(to_theta);
     double p1s = from_index * cos_from;
     double p2s = to_index * cos_to;
@@ -1120,7 +1130,7 @@ template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, HitCtx<D
     double p2p = to_index * cos_from;
     double rs = (p1s - p2s) / (p1s + p2s); rs = rs * rs;
     double rp = (p1p - p2p) / (p1p + p2p); rp = rp * rp;
-    return (rs + rp) / (1.0 + 1.0);
+    return (rs + rp) / (R(1.0) + R(1.0));
 }
 
 /* GeneralRotation::general_rotation for one vector (util.rs:631-666) */
@@ -1129,7 +1139,7 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
 #pragma unroll
     for (int r = 0; r < D; r++)
 #pragma unroll
-        for (int c = 0; c < D; c++) orig[r][c] = (r == c) ? 1.0 : 0.0;
+        for (int c = 0; c < D; c++) orig[r][c] = (r == c) ? R(1.0) : R(0.0);
 #pragma unroll
     for (int r = 0; r < D; r++) { orig[r][0] = self[r]; orig[r][1] = other[r]; }
 #pragma unroll
@@ -1158,7 +1168,7 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
 #pragma unroll
     for (int r = 0; r < D; r++)
 #pragma unroll
-        for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? 1.0 : 0.0;
+        for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? R(1.0) : R(0.0);
     double ca = eu_cos(angle), sa = eu_sin(angle);
     rot[0][0] = ca; rot[0][1] = -sa; rot[1][0] = sa; rot[1][1] = ca;
     double tmp[D][D], fin[D][D];
@@ -1166,7 +1176,7 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int r = 0; r < D; r++)
 #pragma unroll
         for (int c = 0; c < D; c++) {
-            double acc = 0.0;
+            double acc = R(0.0);
 #pragma unroll
             for (int k = 0; k < D; k++) acc = acc + rot[r][k] * res[c][k];
             tmp[r][c] = acc;
@@ -1175,7 +1185,7 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int r = 0; r < D; r++)
 #pragma unroll
         for (int c = 0; c < D; c++) {
-            double acc = 0.0;
+            double acc = R(0.0);
 #pragma unroll
             for (int k = 0; k < D; k++) acc = acc + res[r][k] * tmp[k][c];
             fin[r][c] = acc;
@@ -1183,7 +1193,7 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     double out[D];
 #pragma unroll
     for (int r = 0; r < D; r++) {
-        double acc = 0.0;
+        double acc = R(0.0);
 #pragma unroll
         for (int k = 0; k < D; k++) acc = acc + fin[r][k] * vec[k];
         out[r] = acc;
@@ -1243,14 +1253,14 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c
 #pragma unroll
             for (int k = 0; k < D; k++) nl[k] = C->v[k];            /* = -light_direction, negated at load */
             double angle = angle_between<D>(normal, nl);
-            double ratio = 1.0 - angle / EU_PI_C;
+            double ratio = R(1.0) - angle / EU_PI_C;
             v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
             break;
         }
         case EU_COL_PERLIN: {                                                                 /* d3/entity/surface.rs:22-40 */
             double value = perlin4(S.perlin(C->aux), c.loc[0] / C->v[0], c.loc[1] / C->v[0], c.loc[D > 2 ? 2 : 0] / C->v[0], time_s * C->v[1]);
-            hsv_to_rgb(value * 360.0, 1.0, 1.0, v.r, v.g, v.b);
-            v.a = 1.0;
+            hsv_to_rgb(value * R(360.0), R(1.0), R(1.0), v.r, v.g, v.b);
+            v.a = R(1.0);
             break;
         }
         default: v = mapped_get_color(S, C->aux, c.loc, cnt); break;                          /* surface.rs:536-542 */
@@ -1260,7 +1270,7 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c
         pw[0] = v.r; pw[stride] = v.g; pw[2 * stride] = v.b; pw[3 * stride] = v.a;
         sp++;
     }
-    return Rgba{0.0, 0.0, 0.0, 0.0};     /* not reached: color_first <= color_root */
+    return Rgba{R(0.0), R(0.0), R(0.0), R(0.0)};     /* not reached: color_first <= color_root */
 }
 
 #endif

@@ -26,8 +26,8 @@
 template <int D, int HSCAP /* 0: hit stack in LDS (capacity = hs_cap), else private array of HSCAP */, bool SCENE_IN_LDS>
 __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap,
                                                             EuDevCamera cam, EuDevFrame fr, EuDevCounters *counters,
-                                                            uint32_t *__restrict__ rgba, double *__restrict__ hit_t,
-                                                            double *__restrict__ point_rgb /* single-pixel mode: un-quantised Rgb<F> */) {
+                                                            uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t,
+                                                            eu_f64 *__restrict__ point_rgb /* single-pixel mode: un-quantised Rgb<F> */) {
     extern __shared__ uint64_t lds_dyn[];
     const uint64_t *base = scene_g;
     uint32_t lds_words = 0;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
     int ent = 0;
     uint32_t depth = 0, fsp = 0;
     bool primary = false;
-    double first_hit = -1.0;
+    double first_hit = -R(1.0);
 
     for (;;) {
         /* ---- refill: idle lanes pull the next pixel (wave-aggregated atomic) ---- */
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                     px_y = fr.row_begin + gstrip * 8 + (ry & 7);
                     if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
                         rgba[ry * fr.width + px_x] = 0u;
-                        if (hit_t) hit_t[ry * fr.width + px_x] = -1.0;
+                        if (hit_t) hit_t[ry * fr.width + px_x] = -R(1.0);
                         continue;
                     }
                 } else px_y = fr.row_begin + ry;
@@ -105,14 +105,14 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
             const uint32_t hw = fr.width / 2, hh = fr.height / 2;
             if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
                 rgba[out_idx] = 0xff0000ffu;
-                if (hit_t) hit_t[out_idx] = -1.0;
-                if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
+                if (hit_t) hit_t[out_idx] = -R(1.0);
+                if (point_rgb) { point_rgb[0] = R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = R(0.0); }
                 continue;
             }
             /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
             const int sw = (int)fr.width, sh = (int)fr.height;
-            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
-            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
+            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / R(2.0);
+            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / R(2.0);
             double dl[D];
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -127,29 +127,29 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
             if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
                 const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
                 rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-                if (hit_t) hit_t[out_idx] = -1.0;
-                if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
+                if (hit_t) hit_t[out_idx] = -R(1.0);
+                if (point_rgb) { point_rgb[0] = black ? R(0.0) : R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = black ? R(0.0) : R(1.0); }
                 continue;
             }
             material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
             depth = cam.max_depth;
             fsp = 0;
             primary = true;
-            first_hit = -1.0;
+            first_hit = -R(1.0);
             active = true;
         }
         if (!active) break;   /* no work left for this lane */
         EU_STAMP(s1); EU_ACC(0, s0, s1);
 
         /* ---- TRACE one segment: Universe::trace (universe/mod.rs:149-184) ---- */
-        Rgba ret = {0.0, 0.0, 0.0, 0.0};
+        Rgba ret = {R(0.0), R(0.0), R(0.0), R(0.0)};
         bool returning = false;
 #ifdef EU_PROFILE_PHASES
         unsigned long long s2 = 0;
 #endif
         {
             bool have = false;
-            double best_t = 0.0;
+            double best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0;
             if (depth > 0) {
                 cnt.rays++;
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 for (uint32_t e = 0; e < S.n_entities; e++) {
                     const EuScene::EntityView E = S.entity(e);
                     if (E.surface < 0) continue;
-                    double t = 0.0; uint32_t code = 0;
+                    double t = R(0.0); uint32_t code = 0;
                     const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                     if (n == 0) continue;
                     if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
             }
-            if (primary) { first_hit = have ? best_t : -1.0; primary = false; }
+            if (primary) { first_hit = have ? best_t : -R(1.0); primary = false; }
 #ifdef EU_PROFILE_PHASES
             s2 = __builtin_amdgcn_s_memtime(); ph[1] += s2 - s1;
 #endif
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 const EuScene::EntityView HE = S.entity(best_ent);
                 const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
                 double ratio = reflection_ratio<D>(F, c);
-                ratio = rust_max(rust_min(ratio, 1.0), 0.0);
+                ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));
 
                 bool have_inter = false, need_trans = false;
-                Rgba inter = {0.0, 0.0, 0.0, 0.0};
+                Rgba inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
                 uint32_t spx = 0;
                 double t_o[D], t_d[D];
                 int dest = -1;
-                if (!(ratio >= 1.0)) {                                              /* get_intersection_color */
+                if (!(ratio >= R(1.0))) {                                              /* get_intersection_color */
                     double cst_priv[16];
                     const Rgba sc = surface_color<D>(S, F, c, fr.time_s, cnt, cst_priv, 1u);
                     spx = to_pixel4(sc, cnt);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                     else {
                         threshold_direction<D>(F, c, t_d);
 #pragma unroll
-                        for (int i = 0; i < D; i++) t_o[i] = c.loc[i] + -c.nc[i] * EU_EPS * 128.0;
+                        for (int i = 0; i < D; i++) t_o[i] = c.loc[i] + -c.nc[i] * EU_EPS * R(128.0);
                         dest = c.exiting ? material_at<D>(S, t_o) : (int)best_ent;
                         if (dest >= 0) {
                             material_apply<D>(S, S.entity((uint32_t)ent).material, t_d, true);
@@ -200,14 +200,14 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                         }
                     }
                 }
-                const bool need_refl = !(ratio <= 0.0);                              /* get_reflection_color */
+                const bool need_refl = !(ratio <= R(0.0));                              /* get_reflection_color */
                 double r_o[D], r_d[D];
                 if (need_refl) {
                     const double dn = vdot<D>(c.dir, c.nc);
 #pragma unroll
                     for (int i = 0; i < D; i++) {
-                        r_d[i] = c.nc[i] * -2.0 * dn + c.dir[i];                     /* surface.rs:246-256 */
-                        r_o[i] = c.loc[i] + c.nc[i] * EU_EPS * 128.0;
+                        r_d[i] = c.nc[i] * -R(2.0) * dn + c.dir[i];                     /* surface.rs:246-256 */
+                        r_o[i] = c.loc[i] + c.nc[i] * EU_EPS * R(128.0);
                     }
                 }
                 const uint32_t child_depth = depth - 1;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 cnt.bg++;
                 double pt[D];
 #pragma unroll
-                for (int i = 0; i < D; i++) pt[i] = 0.0 + d[i];
+                for (int i = 0; i < D; i++) pt[i] = R(0.0) + d[i];
                 ret = mapped_get_color(S, S.background, pt, cnt);
                 returning = true;
             }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
         while (returning) {
             if (fsp == 0) {
                 /* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-                const Rgba white = {1.0, 1.0, 1.0, 1.0};
+                const Rgba white = {R(1.0), R(1.0), R(1.0), R(1.0)};
                 const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(ret), into_premultiplied(white)));
                 const uint32_t idx = out_idx;
                 rgba[idx] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;

@@ -33,16 +33,16 @@ template <int D> EU_DEV Rgba ts_background(const EuScene &S, const double *d, La
     cnt.bg++;
     double pt[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) pt[i] = 0.0 + d[i];
+    for (int i = 0; i < D; i++) pt[i] = R(0.0) + d[i];
     return mapped_get_color(S, S.background, pt, cnt);
 }
 
 /* hand a finished colour to whoever waits for it */
 EU_DEV void ts_deliver(EuTsNode *nodes, uint32_t parent, uint32_t slot_mode, const Rgba &c, LaneCounters &cnt,
-                       uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
+                       uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
     const uint32_t mode = slot_mode >> 1;
     if (mode == TS_MODE_ROOT) {             /* trace_unknown: fg.over(white) un-premultiplied, then Rgb::to_pixel (universe/mod.rs:263-269,342) */
-        const Rgba white = {1.0, 1.0, 1.0, 1.0};
+        const Rgba white = {R(1.0), R(1.0), R(1.0), R(1.0)};
         const Rgba out = from_premultiplied(blend_pre(EU_BL_OVER, into_premultiplied(c), into_premultiplied(white)));
         rgba[parent] = to_u8(out.r, cnt) | (to_u8(out.g, cnt) << 8) | (to_u8(out.b, cnt) << 16) | 0xff000000u;
         if (point_rgb) { point_rgb[0] = out.r; point_rgb[1] = out.g; point_rgb[2] = out.b; }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
     for (int k = 0; k < D; k++) { o[k] = in[k]; d[k] = in[D + k]; }
     double distance = in[2 * D];
     EuPathResult res;
-    for (int k = 0; k < 4; k++) { res.location[k] = 0.0; res.direction[k] = 0.0; }
+    for (int k = 0; k < 4; k++) { res.location[k] = R(0.0); res.direction[k] = R(0.0); }
     res.found = 0; res.steps = 0;
     int ent = material_at<D>(S, o);                                         /* universe/mod.rs:280 */
     if (ent >= 0) {
@@ -42,26 +42,26 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
         for (uint32_t step = 0; step <= EU_PATH_MAX_STEPS; step++) {
             /* trace_closest over surfaced entities (universe/mod.rs:194-196) */
             bool have = false;
-            double best_t = 0.0;
+            double best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0;
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuScene::EntityView E = S.entity(e);
                 if (E.surface < 0) continue;
                 if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
-                double t = 0.0; uint32_t code = 0;
+                double t = R(0.0); uint32_t code = 0;
                 const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
             }
             bool moved_on = false;
-            if (have && !(distance - best_t <= 0.0)) {                      /* Surface::get_path, surface.rs:165-167 */
+            if (have && !(distance - best_t <= R(0.0))) {                      /* Surface::get_path, surface.rs:165-167 */
                 HitCtx<D> c;
                 c.finish(best_t, o, d);
                 hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
                 c.classify();
                 double no[D];
 #pragma unroll
-                for (int k = 0; k < D; k++) no[k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
+                for (int k = 0; k < D; k++) no[k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0);
                 const int dest = c.exiting ? material_at<D>(S, no) : (int)best_ent;   /* surface.rs:177-185 */
                 if (dest >= 0) {
                     material_apply<D>(S, S.entity((uint32_t)ent).material, d, true);     /* exit the origin's material, :188 */

@@ -216,7 +216,7 @@ struct EuTsParams {
     EuTsPool P;
     EuDevCounters *counters;
     uint32_t *rgba;
-    double *hit_t_aov, *point_rgb;
+    eu_f64 *hit_t_aov, *point_rgb;
     /* import mode (import_gen != 0xffffffff): the wavefront pipeline's queue of that generation */
     uint32_t import_gen, imp_n_seg, imp_seg_cap, imp_ray_cap;
     const double *imp_ray_od;
@@ -260,7 +260,7 @@ template <int D> EU_DEV void ts_generate(TsState &st, LaneCounters &cnt, int cam
     const uint32_t tid = threadIdx.x;
     const EuTsPool P = ts_pool(q);
     uint32_t *const rgba = q->rgba;
-    double *const hit_t_aov = q->hit_t_aov, *const point_rgb = q->point_rgb;
+    eu_f64 *const hit_t_aov = q->hit_t_aov, *const point_rgb = q->point_rgb;
     const uint32_t max_depth = q->cam.max_depth;
     uint32_t nt = 0;
     if (tid == 0) nt = (uint32_t)atomicAdd(&q->counters->next_item, 1ull);      /* the tile after this one: the round trip hides behind the work */
@@ -289,22 +289,22 @@ template <int D> EU_DEV void ts_generate(TsState &st, LaneCounters &cnt, int cam
                 px_y = q->fr.row_begin + gstrip * 8 + (ry & 7);
                 if (px_y >= q->fr.row_end) {   /* padding rows of the last strip: defined contents */
                     rgba[out_idx] = 0u;
-                    if (hit_t_aov) hit_t_aov[out_idx] = -1.0;
+                    if (hit_t_aov) hit_t_aov[out_idx] = -R(1.0);
                     break;
                 }
             } else px_y = q->fr.row_begin + ry;
         }
-        if (hit_t_aov) hit_t_aov[out_idx] = -1.0;
+        if (hit_t_aov) hit_t_aov[out_idx] = -R(1.0);
         /* Environment::render's cross-hair (universe/mod.rs:321-333) */
         const uint32_t hw = width / 2, hh = height / 2;
         if (q->fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
             rgba[out_idx] = 0xff0000ffu;
-            if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
+            if (point_rgb) { point_rgb[0] = R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = R(0.0); }
             break;
         }
         const int sw = (int)width, sh = (int)height;
-        const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
-        const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
+        const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / R(2.0);
+        const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / R(2.0);
         const double dist = q->cam.dist;
         double dl[D];
 #pragma unroll
@@ -319,7 +319,7 @@ template <int D> EU_DEV void ts_generate(TsState &st, LaneCounters &cnt, int cam
         if (cam_ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
             const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
             rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-            if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
+            if (point_rgb) { point_rgb[0] = black ? R(0.0) : R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = black ? R(0.0) : R(1.0); }
             break;
         }
         EuScene SG;
@@ -384,7 +384,7 @@ template <int D, int HSCAP> EU_DEV void ts_intersect(TsState &st, LaneCounters &
     }
     double o_next[D], d_next[D];
 #pragma unroll
-    for (int k = 0; k < D; k++) { o_next[k] = 0.0; d_next[k] = 0.0; }
+    for (int k = 0; k < D; k++) { o_next[k] = R(0.0); d_next[k] = R(0.0); }
     if (tid < n) {
 #pragma unroll
         for (int k = 0; k < D; k++) { o_next[k] = od[k * EU_TS_CH + tid]; d_next[k] = od[(D + k) * EU_TS_CH + tid]; }
@@ -402,13 +402,13 @@ template <int D, int HSCAP> EU_DEV void ts_intersect(TsState &st, LaneCounters &
             }
             cnt.rays++;
             bool have = false;
-            double best_t = 0.0;
+            double best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0xffffu;
             for (uint32_t e = 0; e < SG.n_entities; e++) {
                 const EuScene::EntityView E = SG.entity(e);
                 if (E.surface < 0) continue;
                 if (E.bound != 0xffffffffu && ray_misses_bound<D>(SG.bounds(E.bound, D), o, d)) continue;
-                double t = 0.0; uint32_t code = 0;
+                double t = R(0.0); uint32_t code = 0;
                 const uint32_t nh = eval_shape<D>(SG, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                 if (nh == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
@@ -416,8 +416,8 @@ template <int D, int HSCAP> EU_DEV void ts_intersect(TsState &st, LaneCounters &
             my_hit_t[i] = best_t;
             my_hit_code[i] = best_code;
             if (gen == 0) {
-                double *const hit_t_aov = q->hit_t_aov;
-                if (hit_t_aov) hit_t_aov[q->P.ray_parent[(size_t)gch * EU_TS_CH + i]] = have ? best_t : -1.0;
+                eu_f64 *const hit_t_aov = q->hit_t_aov;
+                if (hit_t_aov) hit_t_aov[q->P.ray_parent[(size_t)gch * EU_TS_CH + i]] = have ? best_t : -R(1.0);
             }
             const uint32_t key = best_ent < EU_TS_KEYS - 1 ? best_ent : EU_TS_KEYS - 1;
             st.krk[i] = key | (atomicAdd(&st.hist[key], 1u) << 5) | (best_ent << 16);
@@ -432,7 +432,7 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
     const uint32_t tid = threadIdx.x;
     const EuTsPool P = ts_pool(q);
     uint32_t *const rgba = q->rgba;
-    double *const point_rgb = q->point_rgb;
+    eu_f64 *const point_rgb = q->point_rgb;
     const double time_s = q->fr.time_s;
     const uint32_t gen = st.cur_gen, n = st.cur_count;
     const uint32_t gch = blockIdx.x * P.nch + st.cur_chunk;
@@ -460,7 +460,7 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
         double c_o[2][D], c_d[2][D];
         uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_sm[2] = {0, 0};
         uint32_t node_kind = TS_NONE, node_spx = 0, my_parent = 0, my_sm = 0;
-        double node_ratio = 0.0;
+        double node_ratio = R(0.0);
         bool bg_miss = false;
         if (live) {
             const uint32_t parent = rpar[i];
@@ -486,19 +486,19 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
                 const EuScene::EntityView HE = S.entity(hit_ent);
                 const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
                 double ratio = reflection_ratio<D>(F, c);
-                ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
+                ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));                          /* surface.rs:145-147 */
                 bool have_inter = false, need_trans = false;
-                Rgba inter = {0.0, 0.0, 0.0, 0.0};
+                Rgba inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
                 uint32_t spx = 0;
                 int dest = -1;
-                if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
+                if (!(ratio >= R(1.0))) {                                                /* get_intersection_color, surface.rs:62-117 */
                     const Rgba sc = surface_color<D>(S, F, c, time_s, cnt, my_cst, EU_TS_BLOCK);
                     spx = to_pixel4(sc, cnt);
                     if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
                     else {
                         threshold_direction<D>(F, c, c_d[0]);
 #pragma unroll
-                        for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
+                        for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0);
                         dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
                         if (dest >= 0) {
                             material_apply<D>(S, S.entity(ent).material, c_d[0], true);
@@ -507,14 +507,14 @@ template <int D, bool SCENE_LDS> EU_DEV void ts_shade(TsState &st, LaneCounters 
                         }
                     }
                 }
-                const bool need_refl = !(ratio <= 0.0);                                /* get_reflection_color, surface.rs:119-139 */
+                const bool need_refl = !(ratio <= R(0.0));                                /* get_reflection_color, surface.rs:119-139 */
                 const uint32_t rs = need_trans ? 1u : 0u;        /* reflection goes to child slot rs in the arrays */
                 if (need_refl) {
                     const double dn = vdot<D>(c.dir, c.nc);
 #pragma unroll
                     for (int k = 0; k < D; k++) {
-                        const double rd = c.nc[k] * -2.0 * dn + c.dir[k];              /* surface.rs:246-256 */
-                        const double ro = c.loc[k] + c.nc[k] * EU_EPS * 128.0;
+                        const double rd = c.nc[k] * -R(2.0) * dn + c.dir[k];              /* surface.rs:246-256 */
+                        const double ro = c.loc[k] + c.nc[k] * EU_EPS * R(128.0);
                         if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
                     }
                 }
@@ -576,7 +576,7 @@ EU_DEV void ts_resolve(TsState &st, LaneCounters &cnt) {
     TsParamsPtr q = ts_params();
     const EuTsPool P = ts_pool(q);
     uint32_t *const rgba = q->rgba;
-    double *const point_rgb = q->point_rgb;
+    eu_f64 *const point_rgb = q->point_rgb;
     for (uint32_t g = q->cam.max_depth; g-- > 0;) {
         uint32_t chunk = st.node_head[g], count = st.node_fill[g];
         while (chunk != EU_TS_NONE) {

@@ -153,7 +153,7 @@ template <int D> EU_DEV void wf_store_ray(const EuWfBuffers &B, uint32_t buf, ui
 template <int D>
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,
                                                                 EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba,
-                                                                double *__restrict__ hit_t, double *__restrict__ point_rgb) {
+                                                                eu_f64 *__restrict__ hit_t, eu_f64 *__restrict__ point_rgb) {
     extern __shared__ uint64_t lds_dyn[];
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
@@ -195,23 +195,23 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
                     px_y = fr.row_begin + gstrip * 8 + (ry & 7);
                     if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
                         rgba[out_idx] = 0u;
-                        if (hit_t) hit_t[out_idx] = -1.0;
+                        if (hit_t) hit_t[out_idx] = -R(1.0);
                         break;
                     }
                 } else px_y = fr.row_begin + ry;
             }
-            if (hit_t) hit_t[out_idx] = -1.0;
+            if (hit_t) hit_t[out_idx] = -R(1.0);
             /* Environment::render's cross-hair (universe/mod.rs:321-333) */
             const uint32_t hw = fr.width / 2, hh = fr.height / 2;
             if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
                 rgba[out_idx] = 0xff0000ffu;
-                if (point_rgb) { point_rgb[0] = 1.0; point_rgb[1] = 0.0; point_rgb[2] = 0.0; }
+                if (point_rgb) { point_rgb[0] = R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = R(0.0); }
                 break;
             }
             /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
             const int sw = (int)fr.width, sh = (int)fr.height;
-            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / 2.0;
-            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / 2.0;
+            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / R(2.0);
+            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / R(2.0);
             double dl[D];
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
             if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
                 const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
                 rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-                if (point_rgb) { point_rgb[0] = black ? 0.0 : 1.0; point_rgb[1] = 0.0; point_rgb[2] = black ? 0.0 : 1.0; }
+                if (point_rgb) { point_rgb[0] = black ? R(0.0) : R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = black ? R(0.0) : R(1.0); }
                 break;
             }
             material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
 /* ------------------------------------------------------------------ trace_closest */
 template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
 __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
-                                                                      EuWfBuffers B, EuDevCounters *counters, double *__restrict__ hit_t_aov) {
+                                                                      EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
     S.init(scene_g);      /* wave-uniform addresses: the scene arrives through scalar loads */
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
         uint32_t i_next = 0;
         double o_next[D], d_next[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) { o_next[k] = 0.0; d_next[k] = 0.0; }
+        for (int k = 0; k < D; k++) { o_next[k] = R(0.0); d_next[k] = R(0.0); }
         if (v < total) {
             i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v);
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
              * all regular (finite, no zero direction component) evaluates box chains with one product per dot product
              * (chain_matrices_box); should a lane then report a non-finite hit point, the wave's rays are traced once more the generic way. */
             bool have = false;
-            double best_t = 0.0;
+            double best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0xffffffffu;
             bool use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull;
 #ifdef EU_PROFILE_ISECT
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
             for (;;) {
             bool fail = false;
             LaneCounters c1 = cnt;
-            have = false; best_t = 0.0; best_code = 0; best_ent = 0xffffffffu;
+            have = false; best_t = R(0.0); best_code = 0; best_ent = 0xffffffffu;
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuScene::EntityView E = S.entity(e);
                 if (E.surface < 0) continue;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
 #endif
 #ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
                 if (!(E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d))) {
-                    double t = 0.0; uint32_t code = 0;
+                    double t = R(0.0); uint32_t code = 0;
                     const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
                     if (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = e; }
                 }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
                 IS_STAMP(e < 14 ? e : 13);
 #else
                 if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
-                double t = 0.0; uint32_t code = 0;
+                double t = R(0.0); uint32_t code = 0;
                 const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;
             B.hit_ent[i] = best_ent;
-            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -1.0;      /* a primary ray's parent is its pixel */
+            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -R(1.0);      /* a primary ray's parent is its pixel */
             IS_STAMP(15);
         }
     }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const u
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
 template <int D, bool SCENE_LDS>
 __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth /* diagnostic builds: | EU_DEBUG_SKIP_SHADE << 16 */, double time_s,
-                                                                  EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
+                                                                  EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
 #ifdef EU_DEBUG_SKIP      /* EU_DEBUG_SKIP_SHADE bits (in max_depth's high half): 1 constant background, 2 constant opaque surface colour, 4 ratio 0 */
     const uint32_t dbg_shade = max_depth >> 16;
     max_depth &= 0xffffu;
@@ -470,20 +470,20 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     const EuScene::EntityView HE = S.entity(hit_ent);
                     const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
 #ifdef EU_DEBUG_SKIP
-                    double ratio = (dbg_shade & 4u) ? 0.0 : reflection_ratio<D>(F, c);
+                    double ratio = (dbg_shade & 4u) ? R(0.0) : reflection_ratio<D>(F, c);
 #else
                     double ratio = reflection_ratio<D>(F, c);
 #endif
-                    ratio = rust_max(rust_min(ratio, 1.0), 0.0);                          /* surface.rs:145-147 */
+                    ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));                          /* surface.rs:145-147 */
 
                     WF_STAMP(3);
                     bool have_inter = false, need_trans = false;
-                    Rgba inter = {0.0, 0.0, 0.0, 0.0};
+                    Rgba inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
                     uint32_t spx = 0;
                     int dest = -1;
-                    if (!(ratio >= 1.0)) {                                                /* get_intersection_color, surface.rs:62-117 */
+                    if (!(ratio >= R(1.0))) {                                                /* get_intersection_color, surface.rs:62-117 */
 #ifdef EU_DEBUG_SKIP
-                        const Rgba sc = (dbg_shade & 2u) ? Rgba{0.25, 0.5, 0.75, 1.0} : surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
+                        const Rgba sc = (dbg_shade & 2u) ? Rgba{R(0.25), R(0.5), R(0.75), R(1.0)} : surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
 #else
                         const Rgba sc = surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
 #endif
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                             threshold_direction<D>(F, c, c_d[0]);
                             WF_SUB(10);
 #pragma unroll
-                            for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * 128.0;
+                            for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0);
                             dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
                             WF_SUB(11);
                             if (dest >= 0) {
@@ -506,14 +506,14 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                         }
                     }
                     WF_STAMP(4);
-                    const bool need_refl = !(ratio <= 0.0);                                /* get_reflection_color, surface.rs:119-139 */
+                    const bool need_refl = !(ratio <= R(0.0));                                /* get_reflection_color, surface.rs:119-139 */
                     const uint32_t rs = need_trans ? 1u : 0u;        /* reflection goes to child slot rs in the arrays */
                     if (need_refl) {
                         const double dn = vdot<D>(c.dir, c.nc);
 #pragma unroll
                         for (int k = 0; k < D; k++) {
-                            const double rd = c.nc[k] * -2.0 * dn + c.dir[k];              /* surface.rs:246-256 */
-                            const double ro = c.loc[k] + c.nc[k] * EU_EPS * 128.0;
+                            const double rd = c.nc[k] * -R(2.0) * dn + c.dir[k];              /* surface.rs:246-256 */
+                            const double ro = c.loc[k] + c.nc[k] * EU_EPS * R(128.0);
                             if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
                         }
                     }
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
 #pragma unroll
                     for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
 #ifdef EU_DEBUG_SKIP
-                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], (dbg_shade & 1u) ? Rgba{0.1, 0.2, 0.3, 1.0} : ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
+                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], (dbg_shade & 1u) ? Rgba{R(0.1), R(0.2), R(0.3), R(1.0)} : ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
 #else
                     ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
 #endif
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
  * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
  * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass */
 template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, double *__restrict__ point_rgb) {
+__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t node_base = gen * B.ray_cap;
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];

@@ -8,20 +8,43 @@
  * All citations are file:line under /root/reference/src/.
  */
 #define _GNU_SOURCE
-#include "eo_oracle.h"
-#include "eo_math.h"
-
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
 
+#include "eo_math.h"      /* the elementary functions work in f64 whatever F is: before the redefinition below */
+
+/* The reference is generic over F: f64, or f32 with the cargo feature `low_precision` (Cargo.toml:18-20, main.rs:46-49).  The
+ * f32 oracle (libeo_oracle_f32.so, -DEO_LOW_PRECISION) is this file with `double` redefined AFTER the system headers -- API
+ * (eo_oracle.h, included below) and all: the Python loader talks float to that build.  R() types every literal of the path as
+ * F; eo_f64 marks what stays 64-bit (LinearSpace expressions: meval evaluates in f64, material.rs:99-111); each elementary
+ * function's result is rounded to F at once, so that no expression continues in double behind a call. */
+typedef double eo_f64;
+static inline eo_f64 eo_sqrt_f64(eo_f64 x) { return sqrt(x); }
+static inline eo_f64 eo_fmod_f64(eo_f64 x, eo_f64 y) { return fmod(x, y); }
+static inline eo_f64 eo_sin_f64(eo_f64 x) { return eo_sin(x); }
+static inline eo_f64 eo_cos_f64(eo_f64 x) { return eo_cos(x); }
+static inline eo_f64 eo_tan_f64(eo_f64 x) { return eo_tan(x); }
+static inline eo_f64 eo_asin_f64(eo_f64 x) { return eo_asin(x); }
+static inline eo_f64 eo_acos_f64(eo_f64 x) { return eo_acos(x); }
+static inline eo_f64 eo_atan_f64(eo_f64 x) { return eo_atan(x); }
+static inline eo_f64 eo_atan2_f64(eo_f64 y, eo_f64 x) { return eo_atan2(y, x); }
+#define R(x) ((double)(x))
+#ifdef EO_LOW_PRECISION
+#define double float
+#endif
+#include "eo_oracle.h"
+
 #define MAXD 4
-#define EO_EPS128_A 1.0e-6   /* nalgebra 0.8.2 ApproxEq::approx_epsilon for f64 (UNVERIFIED) */
-#define EO_PI_C 3.14159265358979323846264338327950288   /* std::f64::consts::PI */
-#define EO_FRAC_PI_2_C 1.57079632679489661923132169163975144
+#define EO_EPS128_A R(1.0e-6)   /* nalgebra 0.8.2 ApproxEq::approx_epsilon for f64 (UNVERIFIED) */
+#define EO_PI_C R(3.14159265358979323846264338327950288)   /* std::f64::consts::PI */
+#define EO_FRAC_PI_2_C R(1.57079632679489661923132169163975144)
 
 /* ------------------------------------------------------------------ object model */
 
@@ -53,7 +76,7 @@ static const int FN_ARITY[FN_COUNT] = { 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 2, 1
 
 typedef struct expr_node {
     int kind, fn;
-    double num;
+    eo_f64 num;
     char var[16];
     struct expr_node *l, *r;
 } expr_node;
@@ -137,13 +160,9 @@ const char *eo_last_error(const eo_scene *s) { return s->err; }
  * by eo_render; the shipped oracle (the timed CPU baseline) is built without them. */
 #ifdef EO_USE_LIBM      /* variant build: the platform libm (what Rust's f64::acos etc. call) instead of eo_math.h -- measures how far
                          * a <= 1 ulp difference in the elementary functions moves the rendered bytes (tests/test_oracle_libm.py) */
-#define eo_acos acos
-#define eo_asin asin
-#define eo_sin sin
-#define eo_cos cos
-#define eo_tan tan
-#define eo_atan atan
-#define eo_atan2 atan2
+#define EO_FN(name) name
+#else
+#define EO_FN(name) eo_##name
 #endif
 static unsigned long long eo_fl_total[4];
 static pthread_mutex_t eo_fl_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -153,24 +172,28 @@ static __thread unsigned long long eo_fl[4];
 #define FLD(n) (eo_fl[1] += (unsigned long long)(n))
 #define FLS(n) (eo_fl[2] += (unsigned long long)(n))
 #define FLT(n) (eo_fl[3] += (unsigned long long)(n))
-static inline double eo_cnt_t_(double v) { FLT(1); return v; }
-static inline double eo_cnt_s_(double v) { FLS(1); return v; }
-static inline double eo_cnt_d_(double v) { FLD(1); return v; }
-#define eo_acos(x) eo_cnt_t_(eo_acos(x))
-#define eo_asin(x) eo_cnt_t_(eo_asin(x))
-#define eo_sin(x) eo_cnt_t_(eo_sin(x))
-#define eo_cos(x) eo_cnt_t_(eo_cos(x))
-#define eo_tan(x) eo_cnt_t_(eo_tan(x))
-#define eo_atan(x) eo_cnt_t_(eo_atan(x))
-#define eo_atan2(y, x) eo_cnt_t_(eo_atan2(y, x))
-#define sqrt(x) eo_cnt_s_(sqrt(x))
-#define fmod(x, y) eo_cnt_d_(fmod(x, y))
+static inline eo_f64 eo_cnt_t_(eo_f64 v) { FLT(1); return v; }
+static inline eo_f64 eo_cnt_s_(eo_f64 v) { FLS(1); return v; }
+static inline eo_f64 eo_cnt_d_(eo_f64 v) { FLD(1); return v; }
 #else
 #define FL(n) ((void)0)
 #define FLD(n) ((void)0)
 #define FLS(n) ((void)0)
 #define FLT(n) ((void)0)
+#define eo_cnt_t_(v) (v)
+#define eo_cnt_s_(v) (v)
+#define eo_cnt_d_(v) (v)
 #endif
+/* every elementary function of the path: evaluated in f64 (eo_math.h or libm), counted, rounded to F at once */
+#define eo_acos(x) ((double)eo_cnt_t_(EO_FN(acos)(x)))
+#define eo_asin(x) ((double)eo_cnt_t_(EO_FN(asin)(x)))
+#define eo_sin(x) ((double)eo_cnt_t_(EO_FN(sin)(x)))
+#define eo_cos(x) ((double)eo_cnt_t_(EO_FN(cos)(x)))
+#define eo_tan(x) ((double)eo_cnt_t_(EO_FN(tan)(x)))
+#define eo_atan(x) ((double)eo_cnt_t_(EO_FN(atan)(x)))
+#define eo_atan2(y, x) ((double)eo_cnt_t_(EO_FN(atan2)(y, x)))
+#define sqrt(x) ((double)eo_cnt_s_(sqrt(x)))
+#define fmod(x, y) ((double)eo_cnt_d_(fmod(x, y)))
 
 /* ------------------------------------------------------------------ vectors (nalgebra 0.8.2) */
 /* dot / norm summation order x -> w (UNVERIFIED for nalgebra 0.8.2) */
@@ -204,19 +227,19 @@ static void v_cross3(const double *a, const double *b, double *o) {
 static double angle_between(int D, const double *a, const double *b) {
     FL(1); FLD(1);
     double result = eo_acos(v_dot(D, a, b) / (v_norm(D, a) * v_norm(D, b)));
-    return eo_isnan(result) ? 0.0 : result;
+    return eo_isnan(result) ? R(0.0) : result;
 }
 
 /* Rust f64::signum: NaN -> NaN, +-0 -> +-1 */
-static double rust_signum(double x) { if (eo_isnan(x)) return x; return signbit(x) ? -1.0 : 1.0; }
+static double rust_signum(double x) { if (eo_isnan(x)) return x; return signbit(x) ? -R(1.0) : R(1.0); }
 static double rust_min(double a, double b) { if (eo_isnan(a)) return b; if (eo_isnan(b)) return a; return a < b ? a : b; }
 static double rust_max(double a, double b) { if (eo_isnan(a)) return b; if (eo_isnan(b)) return a; return a > b ? a : b; }
 
 /* util.rs:287-299 */
 static double remainder_f(double a, double b) {
     double rem = fmod(a, b);
-    if (rem == 0.0) return 0.0;
-    if (a < 0.0) return b + rem;
+    if (rem == R(0.0)) return R(0.0);
+    if (a < R(0.0)) return b + rem;
     return rem;
 }
 static int64_t remainder_i(int64_t a, int64_t b) {
@@ -237,7 +260,7 @@ int eo_shape_sphere(eo_scene *s, const double *center, double radius) {   /* sha
 }
 
 int eo_shape_hyperplane(eo_scene *s, const double *normal, double constant) {   /* shape.rs:750-759 */
-    if (!(v_nsq(s->dim, normal) > 0.0)) return fail(s, "Cannot have a normal with length of 0.");
+    if (!(v_nsq(s->dim, normal) > R(0.0))) return fail(s, "Cannot have a normal with length of 0.");
     int h; obj *o = new_obj(s, K_SHAPE, SH_PLANE, &h);
     v_copy(s->dim, normal, o->a); o->r = constant;
     return h;
@@ -285,10 +308,10 @@ int eo_shape_cuboid(eo_scene *s, const double *center, const double *abc) {
     int D = s->dim;
     if (D != 3 && D != 4) return fail(s, "cuboid: 3-D or 4-D only");
     double half[MAXD];
-    for (int i = 0; i < D; i++) half[i] = abc[i] / 2.0;
+    for (int i = 0; i < D; i++) half[i] = abc[i] / R(2.0);
     int shapes[8], n = 0;
     double axis[MAXD][MAXD] = {{0}};
-    for (int i = 0; i < D; i++) axis[i][i] = 1.0;
+    for (int i = 0; i < D; i++) axis[i][i] = R(1.0);
     for (int ax = 0; ax < D; ax++) {
         for (int sgn = 0; sgn < 2; sgn++) {
             double off[MAXD], pt[MAXD];
@@ -316,8 +339,8 @@ int eo_shape_cuboid(eo_scene *s, const double *center, const double *abc) {
 }
 
 int eo_shape_cylinder(eo_scene *s, const double *center, const double *direction, double radius) {   /* shape.rs:893-904 */
-    if (!(v_nsq(s->dim, direction) > 0.0)) return fail(s, "Cannot have a direction with length of 0.");
-    if (!(radius > 0.0)) return fail(s, "The radius must be positive.");
+    if (!(v_nsq(s->dim, direction) > R(0.0))) return fail(s, "Cannot have a direction with length of 0.");
+    if (!(radius > R(0.0))) return fail(s, "The radius must be positive.");
     int h; obj *o = new_obj(s, K_SHAPE, SH_CYLINDER, &h);
     v_copy(s->dim, center, o->a);
     v_normalize(s->dim, direction, o->b);
@@ -328,7 +351,7 @@ int eo_shape_cylinder_with_height(eo_scene *s, const double *center, const doubl
     int D = s->dim;
     double nd[MAXD], off[MAXD], pt[MAXD];
     v_normalize(D, direction, nd);
-    double half_height = height / (1.0 + 1.0);
+    double half_height = height / (R(1.0) + R(1.0));
     int shapes[3];
     shapes[0] = eo_shape_cylinder(s, center, direction, radius);
     if (shapes[0] < 0) return shapes[0];
@@ -572,17 +595,17 @@ static void make_hit(int D, const double *loc, const double *dir, double tt, hit
 /* quadratic shared by sphere (shape.rs:667-693) and cylinder (shape.rs:962-988) */
 static int quad_roots(double a, double b, double c, double *t_first, double *t_second, int *has_second) {
     FL(4);
-    double d = b * b - 4.0 * a * c;
-    if (d < 0.0) return 0;
+    double d = b * b - R(4.0) * a * c;
+    if (d < R(0.0)) return 0;
     FL(4); FLD(2);
     double d_sqrt = sqrt(d);
-    double t1 = (-b - d_sqrt) / (2.0 * a);
-    double t2 = (-b + d_sqrt) / (2.0 * a);
+    double t1 = (-b - d_sqrt) / (R(2.0) * a);
+    double t2 = (-b + d_sqrt) / (R(2.0) * a);
     int has_first = 0; *has_second = 0;
-    if (t1 >= 0.0) {
+    if (t1 >= R(0.0)) {
         *t_first = t1; has_first = 1;
-        if (t2 >= 0.0) { *t_second = t2; *has_second = 1; }
-    } else if (t2 >= 0.0) {
+        if (t2 >= R(0.0)) { *t_second = t2; *has_second = 1; }
+    } else if (t2 >= R(0.0)) {
         *t_first = t2; has_first = 1;
     }
     return has_first;
@@ -599,7 +622,7 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
         double rel[MAXD]; v_sub(D, loc, sh->a, rel);
         double a = v_nsq(D, dir);
         FL(3);
-        double b = 2.0 * v_dot(D, dir, rel);
+        double b = R(2.0) * v_dot(D, dir, rel);
         double c = v_nsq(D, rel) - sh->r * sh->r;
         double t1, t2; int has2;
         if (!quad_roots(a, b, c, &t1, &t2, &has2)) break;
@@ -615,7 +638,7 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
     case SH_PLANE: case SH_HALFSPACE: {                                   /* shape.rs:779-809, 843-870 */
         FL(1); FLD(1);
         double tt = -(v_dot(D, sh->a, loc) + sh->r) / v_dot(D, sh->a, dir);
-        if (tt < 0.0) break;
+        if (tt < R(0.0)) break;
         hit_t *h = &p->imm[p->n_imm++];
         make_hit(D, loc, dir, tt, h);
         v_copy(D, sh->a, h->normal);
@@ -629,7 +652,7 @@ static provider *universe_intersect(tctx *t, const double *loc, const double *di
         v_scale(D, sh->b, v_dot(D, delta, sh->b), tmp); v_sub(D, delta, tmp, c_vec);
         double a = v_nsq(D, a_vec);
         FL(4);
-        double b = (1.0 + 1.0) * v_dot(D, a_vec, c_vec);
+        double b = (R(1.0) + R(1.0)) * v_dot(D, a_vec, c_vec);
         double c = v_nsq(D, c_vec) - sh->r * sh->r;
         double t1, t2; int has2;
         if (!quad_roots(a, b, c, &t1, &t2, &has2)) break;
@@ -680,7 +703,7 @@ static expr_node *ep_atom(eparser *p) {
     }
     if (isdigit((unsigned char)c) || c == '.') {
         char *end;
-        double v = strtod(p->s + p->pos, &end);
+        eo_f64 v = strtod(p->s + p->pos, &end);
         if (end == p->s + p->pos) { p->ok = 0; return NULL; }
         p->pos = (int)(end - p->s);
         expr_node *e = mk(EX_NUM, NULL, NULL); e->num = v; return e;
@@ -706,7 +729,7 @@ static expr_node *ep_atom(eparser *p) {
             p->pos++;
             expr_node *e = mk(EX_FUNC, a0, a1); e->fn = fn; return e;
         }
-        if (!strcmp(name, "pi")) { expr_node *e = mk(EX_NUM, NULL, NULL); e->num = EO_PI_C; return e; }
+        if (!strcmp(name, "pi")) { expr_node *e = mk(EX_NUM, NULL, NULL); e->num = 3.14159265358979323846264338327950288; return e; }
         if (!strcmp(name, "e")) { expr_node *e = mk(EX_NUM, NULL, NULL); e->num = 2.71828182845904523536028747135266250; return e; }
         expr_node *e = mk(EX_VAR, NULL, NULL); strcpy(e->var, name); return e;
     }
@@ -755,18 +778,22 @@ static expr_node *parse_expr(const char *s) {
     return e;
 }
 
+/* LinearSpace expressions are evaluated in f64 whatever F is (meval; the result is cast to F, material.rs:99-111) */
+static eo_f64 expr_min(eo_f64 a, eo_f64 b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
+static eo_f64 expr_max(eo_f64 a, eo_f64 b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
+static eo_f64 expr_signum(eo_f64 x) { if (x != x) return x; return signbit(x) ? -1.0 : 1.0; }
 /* x^y restricted to integral |y| <= 64 (repeated multiplication; meval uses powf -- deviation) */
-static double pow_int(double x, double y) {
+static eo_f64 pow_int(eo_f64 x, eo_f64 y) {
     if (!(y == floor(y)) || fabs(y) > 64.0) return NAN;
     int n = (int)fabs(y);
-    double r = 1.0;
+    eo_f64 r = 1.0;
     FL(n);
     for (int i = 0; i < n; i++) r = r * x;
     if (y < 0.0) FLD(1);
     return (y < 0.0) ? 1.0 / r : r;
 }
 
-static double eval_expr(const expr_node *e, const char *legend, const double *ctx, int D, int *err) {
+static eo_f64 eval_expr(const expr_node *e, const char *legend, const eo_f64 *ctx, int D, int *err) {
     switch (e->kind) {
     case EX_NUM: return e->num;
     case EX_VAR:
@@ -776,27 +803,27 @@ static double eval_expr(const expr_node *e, const char *legend, const double *ct
     case EX_SUB: FL(1); return eval_expr(e->l, legend, ctx, D, err) - eval_expr(e->r, legend, ctx, D, err);
     case EX_MUL: FL(1); return eval_expr(e->l, legend, ctx, D, err) * eval_expr(e->r, legend, ctx, D, err);
     case EX_DIV: FLD(1); return eval_expr(e->l, legend, ctx, D, err) / eval_expr(e->r, legend, ctx, D, err);
-    case EX_REM: return fmod(eval_expr(e->l, legend, ctx, D, err), eval_expr(e->r, legend, ctx, D, err));
+    case EX_REM: return eo_fmod_f64(eval_expr(e->l, legend, ctx, D, err), eval_expr(e->r, legend, ctx, D, err));
     case EX_POW: return pow_int(eval_expr(e->l, legend, ctx, D, err), eval_expr(e->r, legend, ctx, D, err));
     case EX_NEG: return -eval_expr(e->l, legend, ctx, D, err);
     default: {
-        double x = eval_expr(e->l, legend, ctx, D, err);
-        double y = e->r ? eval_expr(e->r, legend, ctx, D, err) : 0.0;
+        eo_f64 x = eval_expr(e->l, legend, ctx, D, err);
+        eo_f64 y = e->r ? eval_expr(e->r, legend, ctx, D, err) : 0.0;
         switch (e->fn) {
-        case FN_SQRT: return sqrt(x);
+        case FN_SQRT: return eo_sqrt_f64(x);
         case FN_ABS: return fabs(x);
         case FN_FLOOR: return floor(x);
         case FN_CEIL: return ceil(x);
-        case FN_MIN: return rust_min(x, y);
-        case FN_MAX: return rust_max(x, y);
-        case FN_SIN: return eo_sin(x);
-        case FN_COS: return eo_cos(x);
-        case FN_TAN: return eo_tan(x);
-        case FN_ASIN: return eo_asin(x);
-        case FN_ACOS: return eo_acos(x);
-        case FN_ATAN: return eo_atan(x);
-        case FN_ATAN2: return eo_atan2(x, y);
-        default: return rust_signum(x);
+        case FN_MIN: return expr_min(x, y);
+        case FN_MAX: return expr_max(x, y);
+        case FN_SIN: return eo_sin_f64(x);
+        case FN_COS: return eo_cos_f64(x);
+        case FN_TAN: return eo_tan_f64(x);
+        case FN_ASIN: return eo_asin_f64(x);
+        case FN_ACOS: return eo_acos_f64(x);
+        case FN_ATAN: return eo_atan_f64(x);
+        case FN_ATAN2: return eo_atan2_f64(x, y);
+        default: return expr_signum(x);
         }
     }
     }
@@ -847,12 +874,12 @@ int eo_material_linear_space(eo_scene *s, const char *legend, const int *transfo
  * vector BEFORE any component is overwritten. */
 static void transform_with(tctx *t, const obj *tr, const char *legend, double *v, int inverse) {
     int D = t->D;
-    double ctx[MAXD];
-    v_copy(D, v, ctx);
+    eo_f64 ctx[MAXD];
+    for (int i = 0; i < D; i++) ctx[i] = v[i];
     for (int i = 0; i < D; i++) {
         int err = 0;
         const obj *e = tr->children[i];
-        v[i] = eval_expr(inverse ? e->ex_inv : e->ex, legend, ctx, D, &err);
+        v[i] = (double)eval_expr(inverse ? e->ex_inv : e->ex, legend, ctx, D, &err);
         if (err) t->stats.errors++;
     }
 }
@@ -867,7 +894,7 @@ static void material_exit(tctx *t, const obj *m, double *dir) {           /* mat
 
 /* ------------------------------------------------------------------ palette 0.2.1 (UNVERIFIED) */
 
-static double clamp01(double v) { if (v < 0.0) return 0.0; if (v > 1.0) return 1.0; return v; }
+static double clamp01(double v) { if (v < R(0.0)) return R(0.0); if (v > R(1.0)) return R(1.0); return v; }
 static int is_normal(double x) { return isnormal(x); }
 
 typedef struct { double r, g, b, a; } pre_t;   /* PreAlpha<Rgb<F>, F> */
@@ -882,13 +909,13 @@ static rgba_t from_premultiplied(pre_t p) {
     double alpha = clamp01(p.a);
     rgba_t c;
     if (is_normal(alpha)) { FLD(3); c.r = p.r / alpha; c.g = p.g / alpha; c.b = p.b / alpha; }
-    else { c.r = 0.0; c.g = 0.0; c.b = 0.0; }
+    else { c.r = R(0.0); c.g = R(0.0); c.b = R(0.0); }
     c.a = alpha;
     return c;
 }
 
 static double blend_chan(int fn, double a, double b, double sa, double da) {
-    const double one = 1.0, two = 2.0;
+    const double one = R(1.0), two = R(2.0);
 #ifdef EO_COUNT_FLOPS
     {   /* adds / multiplies of the formula taken (the divisions of dodge / burn / soft_light are counted with them: 1-2 each) */
         static const unsigned char BLEND_FL[BL_COUNT] = { 3, 1, 2, 5, 7, 1, 9, 3, 10, 10, 10, 13, 13, 10, 16, 6, 4, 0 };
@@ -921,11 +948,11 @@ static double blend_chan(int fn, double a, double b, double sa, double da) {
         if (a * two <= sa) return two * a * b + a * (one - da) + b * (one - sa);
         return a * (one + da) + b * (one + sa) - two * a * b - sa * da;
     case BL_SOFT_LIGHT: {
-        double m = is_normal(da) ? b / da : 0.0;
+        double m = is_normal(da) ? b / da : R(0.0);
         if (a * two <= sa) return b * (sa + (two * a - sa) * (one - m)) + a * (one - da) + b * (one - sa);
-        if (b * 4.0 <= da) {
+        if (b * R(4.0) <= da) {
             double m2 = m * m, m3 = m2 * m;
-            return da * (two * a - sa) * (m3 * 16.0 - m2 * 12.0 - m * 3.0) + a - a * da + b;
+            return da * (two * a - sa) * (m3 * R(16.0) - m2 * R(12.0) - m * R(3.0)) + a - a * da + b;
         }
         return da * (two * a - sa) * (sqrt(m) - m) + a - a * da + b;
     }
@@ -937,9 +964,9 @@ static double blend_alpha(int fn, double sa, double da) {
     FL(3);
     switch (fn) {
     case BL_INSIDE: return clamp01(sa * da);
-    case BL_OUTSIDE: return clamp01(sa * (1.0 - da));
+    case BL_OUTSIDE: return clamp01(sa * (R(1.0) - da));
     case BL_ATOP: return clamp01(da);
-    case BL_XOR: return clamp01(sa + da - 2.0 * sa * da);
+    case BL_XOR: return clamp01(sa + da - R(2.0) * sa * da);
     case BL_PLUS: return clamp01(sa + da);
     default: return clamp01(sa + da - sa * da);
     }
@@ -957,14 +984,14 @@ static rgba_t blend_rgba(int fn, rgba_t s, rgba_t d) { return from_premultiplied
 
 /* util.rs:265-285 */
 static rgba_t combine_palette_color(rgba_t a, rgba_t b, double a_ratio) {
-    if (a_ratio <= 0.0) return b;
-    if (a_ratio >= 1.0) return a;
+    if (a_ratio <= R(0.0)) return b;
+    if (a_ratio >= R(1.0)) return a;
     rgba_t o;
     FL(16);
-    o.r = a.r * a_ratio + b.r * (1.0 - a_ratio);
-    o.g = a.g * a_ratio + b.g * (1.0 - a_ratio);
-    o.b = a.b * a_ratio + b.b * (1.0 - a_ratio);
-    o.a = a.a * a_ratio + b.a * (1.0 - a_ratio);
+    o.r = a.r * a_ratio + b.r * (R(1.0) - a_ratio);
+    o.g = a.g * a_ratio + b.g * (R(1.0) - a_ratio);
+    o.b = a.b * a_ratio + b.b * (R(1.0) - a_ratio);
+    o.a = a.a * a_ratio + b.a * (R(1.0) - a_ratio);
     return o;
 }
 
@@ -972,32 +999,32 @@ static rgba_t combine_palette_color(rgba_t a, rgba_t b, double a_ratio) {
  * in NumCast; the oracle writes 0 and counts it. */
 static uint8_t to_u8(tctx *t, double c) {
     FL(1);
-    double v = clamp01(c) * 255.0;
+    double v = clamp01(c) * R(255.0);
     if (eo_isnan(v)) { if (t) t->stats.nan_pixels++; return 0; }
     return (uint8_t)v;
 }
 static void to_pixel4(tctx *t, rgba_t c, uint8_t *px) { px[0] = to_u8(t, c.r); px[1] = to_u8(t, c.g); px[2] = to_u8(t, c.b); px[3] = to_u8(t, c.a); }
-static rgba_t new_u8(const uint8_t *px) { FLD(4); rgba_t c = { (double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0, (double)px[3] / 255.0 }; return c; }
+static rgba_t new_u8(const uint8_t *px) { FLD(4); rgba_t c = { (double)px[0] / R(255.0), (double)px[1] / R(255.0), (double)px[2] / R(255.0), (double)px[3] / R(255.0) }; return c; }
 
 /* Hsv -> Rgb, RgbHue::to_positive_degrees (palette 0.2.1, UNVERIFIED) */
 static void hsv_to_rgb(double hue, double saturation, double value, double *r, double *g, double *b) {
     double deg = hue;
-    if (fabs(deg) < 1.0e9) {       /* guard for the while loops; larger hues fall through like NaN */
-        while (deg >= 360.0) deg = deg - 360.0;
-        while (deg < 0.0) deg = deg + 360.0;
+    if (fabs(deg) < R(1.0e9)) {       /* guard for the while loops; larger hues fall through like NaN */
+        while (deg >= R(360.0)) deg = deg - R(360.0);
+        while (deg < R(0.0)) deg = deg + R(360.0);
     }
     FL(7); FLD(1);
     double c = value * saturation;
-    double h = deg / 60.0;
-    double x = c * (1.0 - fabs(fmod(h, 2.0) - 1.0));
+    double h = deg / R(60.0);
+    double x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
     double m = value - c;
     double red, green, blue;
-    if (h >= 0.0 && h < 1.0) { red = c; green = x; blue = 0.0; }
-    else if (h >= 1.0 && h < 2.0) { red = x; green = c; blue = 0.0; }
-    else if (h >= 2.0 && h < 3.0) { red = 0.0; green = c; blue = x; }
-    else if (h >= 3.0 && h < 4.0) { red = 0.0; green = x; blue = c; }
-    else if (h >= 4.0 && h < 5.0) { red = x; green = 0.0; blue = c; }
-    else { red = c; green = 0.0; blue = x; }
+    if (h >= R(0.0) && h < R(1.0)) { red = c; green = x; blue = R(0.0); }
+    else if (h >= R(1.0) && h < R(2.0)) { red = x; green = c; blue = R(0.0); }
+    else if (h >= R(2.0) && h < R(3.0)) { red = R(0.0); green = c; blue = x; }
+    else if (h >= R(3.0) && h < R(4.0)) { red = R(0.0); green = x; blue = c; }
+    else if (h >= R(4.0) && h < R(5.0)) { red = x; green = R(0.0); blue = c; }
+    else { red = c; green = R(0.0); blue = x; }
     *r = red + m; *g = green + m; *b = blue + m;
 }
 void eo_rgba_from_hsva(double hue, double s, double v, double a, double *out) {   /* scene.rs:663-667 */
@@ -1022,7 +1049,7 @@ static void perlin_build_perm(uint32_t seed, uint8_t *perm512) {
     }
     for (int i = 0; i < 512; i++) perm512[i] = p[i & 255];
 }
-static double pfade(double t) { FL(7); return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+static double pfade(double t) { FL(7); return t * t * t * (t * (t * R(6.0) - R(15.0)) + R(10.0)); }
 static double plerp(double t, double a, double b) { FL(3); return a + t * (b - a); }
 static double pgrad4(int hash, double x, double y, double z, double w) {
     FL(2);
@@ -1032,7 +1059,7 @@ static double pgrad4(int hash, double x, double y, double z, double w) {
     double c = (h < 8) ? z : w;
     return ((h & 1) ? -a : a) + ((h & 2) ? -b : b) + ((h & 4) ? -c : c);
 }
-static int pcell(double f) { double m = fmod(f, 256.0); return (m == m) ? (((int)m) & 255) : 0; }
+static int pcell(double f) { double m = fmod(f, R(256.0)); return (m == m) ? (((int)m) & 255) : 0; }
 static double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
     double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
     int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
@@ -1049,7 +1076,7 @@ static double perlin4(const uint8_t *perm, double x, double y, double z, double 
     for (int c = 0; c < 8; c++) lx[c] = plerp(u, n[2 * c], n[2 * c + 1]);
     for (int c = 0; c < 4; c++) ly[c] = plerp(v, lx[2 * c], lx[2 * c + 1]);
     for (int c = 0; c < 2; c++) lz[c] = plerp(s, ly[2 * c], ly[2 * c + 1]);
-    return 0.87 * plerp(q, lz[0], lz[1]);
+    return R(0.87) * plerp(q, lz[0], lz[1]);
 }
 
 /* ------------------------------------------------------------------ surface providers */
@@ -1122,10 +1149,10 @@ int eo_default_camera(int dim, const double *loc, eo_camera *c) {   /* d3/entity
     memset(c, 0, sizeof *c);
     c->dim = dim;
     if (loc) for (int i = 0; i < dim; i++) c->location[i] = loc[i];
-    c->forward[0] = 1.0;
-    c->up[2 < dim ? 2 : dim - 1] = 1.0;
-    if (dim == 2) { c->up[0] = 0.0; c->up[1] = 1.0; }
-    c->left[1] = 1.0;
+    c->forward[0] = R(1.0);
+    c->up[2 < dim ? 2 : dim - 1] = R(1.0);
+    if (dim == 2) { c->up[0] = R(0.0); c->up[1] = R(1.0); }
+    c->left[1] = R(1.0);
     c->fov_deg = 90;
     c->max_depth = 10;
     return 0;
@@ -1151,13 +1178,13 @@ static void uv_eval(const obj *uv, const double *point, double *u, double *v) {
     v_sub(3, point, uv->a, p);
     v_normalize(3, p, pn);
     FL(3); FLD(2);
-    *u = 0.5 + eo_atan2(pn[1], pn[0]) / (2.0 * EO_PI_C);
-    *v = 0.5 - eo_asin(pn[2]) / EO_PI_C;
+    *u = R(0.5) + eo_atan2(pn[1], pn[0]) / (R(2.0) * EO_PI_C);
+    *v = R(0.5) - eo_asin(pn[2]) / EO_PI_C;
 }
 
 /* NumCast::from(f64) -> u32: None (panic) if NaN or outside the u32 range, else truncation */
 static int cast_u32(tctx *t, double x, uint32_t *out) {
-    if (!(x > -1.0 && x < 4294967296.0)) { t->stats.errors++; *out = 0; return 0; }
+    if (!(x > -R(1.0) && x < R(4294967296.0))) { t->stats.errors++; *out = 0; return 0; }
     *out = (uint32_t)x;
     return 1;
 }
@@ -1172,11 +1199,11 @@ static rgba_t texture_eval(tctx *t, const obj *tx, double pu, double pv) {
         xi = (uint32_t)remainder_i((int64_t)xi, (int64_t)W);
         yi = (uint32_t)remainder_i((int64_t)yi, (int64_t)H);
         const uint8_t *px = tx->pixels + ((size_t)yi * W + xi) * 4;
-        rgba_t c = { (double)px[0] / 255.0, (double)px[1] / 255.0, (double)px[2] / 255.0, (double)px[3] / 255.0 };
+        rgba_t c = { (double)px[0] / R(255.0), (double)px[1] / R(255.0), (double)px[2] / R(255.0), (double)px[3] / R(255.0) };
         return c;
     }
     FL(6 + 4 + 2 + 4 * 9); FLD(4);            /* coordinates, offsets, the two weights, 4 channels x 9 */
-    double x = pu * (double)W - 0.5, y = pv * (double)H - 0.5;             /* surface.rs:453-489 */
+    double x = pu * (double)W - R(0.5), y = pv * (double)H - R(0.5);             /* surface.rs:453-489 */
     double ox = x - floor(x), oy = y - floor(y);
     static const double OFF[4][2] = { {0, 0}, {1, 0}, {0, 1}, {1, 1} };
     const uint8_t *px[4];
@@ -1190,8 +1217,8 @@ static rgba_t texture_eval(tctx *t, const obj *tx, double pu, double pv) {
     }
     double data[4];
     for (int k = 0; k < 4; k++)
-        data[k] = (((double)px[0][k] * (1.0 - ox) + (double)px[1][k] * ox) * (1.0 - oy) +
-                   ((double)px[2][k] * (1.0 - ox) + (double)px[3][k] * ox) * oy) / 255.0;
+        data[k] = (((double)px[0][k] * (R(1.0) - ox) + (double)px[1][k] * ox) * (R(1.0) - oy) +
+                   ((double)px[2][k] * (R(1.0) - ox) + (double)px[3][k] * ox) * oy) / R(255.0);
     rgba_t c = { data[0], data[1], data[2], data[3] };
     return c;
 }
@@ -1215,7 +1242,7 @@ typedef struct {           /* TracingContext, shape.rs:111-125 */
 /* util.rs:631-666, for one vector */
 static void general_rotation(int D, const double *self, const double *other, double angle, double *vec) {
     double orig[MAXD][MAXD], res[MAXD][MAXD];     /* [row][col] */
-    for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) orig[r][c] = (r == c) ? 1.0 : 0.0;
+    for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) orig[r][c] = (r == c) ? R(1.0) : R(0.0);
     for (int r = 0; r < D; r++) { orig[r][0] = self[r]; orig[r][1] = other[r]; }
     memcpy(res, orig, sizeof res);
     for (int i = 1; i < D; i++) {
@@ -1232,24 +1259,24 @@ static void general_rotation(int D, const double *self, const double *other, dou
         for (int r = 0; r < D; r++) res[r][i] = nc[r];
     }
     double rot[MAXD][MAXD];
-    for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? 1.0 : 0.0;
+    for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? R(1.0) : R(0.0);
     double ca = eo_cos(angle), sa = eo_sin(angle);
     rot[0][0] = ca; rot[0][1] = -sa; rot[1][0] = sa; rot[1][1] = ca;
     double tmp[MAXD][MAXD], fin[MAXD][MAXD];
     FL(2 * (2 * D * D * D) + 2 * D * D);      /* two matrix products and the matrix-vector product */
     for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) {           /* rotation * result^T */
-        double acc = 0.0;
+        double acc = R(0.0);
         for (int k = 0; k < D; k++) acc = acc + rot[r][k] * res[c][k];
         tmp[r][c] = acc;
     }
     for (int r = 0; r < D; r++) for (int c = 0; c < D; c++) {           /* result * (...) */
-        double acc = 0.0;
+        double acc = R(0.0);
         for (int k = 0; k < D; k++) acc = acc + res[r][k] * tmp[k][c];
         fin[r][c] = acc;
     }
     double out[MAXD];
     for (int r = 0; r < D; r++) {
-        double acc = 0.0;
+        double acc = R(0.0);
         for (int k = 0; k < D; k++) acc = acc + fin[r][k] * vec[k];
         out[r] = acc;
     }
@@ -1258,7 +1285,7 @@ static void general_rotation(int D, const double *self, const double *other, dou
 
 static double reflection_ratio(tctx *t, const obj *p, const trace_ctx *c) {
     int D = t->D;
-    if (p->sub == RATIO_UNIFORM) return c->exiting ? 0.0 : p->p0;          /* surface.rs:200-211 */
+    if (p->sub == RATIO_UNIFORM) return c->exiting ? R(0.0) : p->p0;          /* surface.rs:200-211 */
     double normal[MAXD];                                                    /* surface.rs:213-244 */
     v_neg(D, c->normal_closer, normal);
     double from_theta = angle_between(D, c->intersection.direction, normal);
@@ -1266,7 +1293,7 @@ static double reflection_ratio(tctx *t, const obj *p, const trace_ctx *c) {
     if (c->exiting) { from_index = p->p0; to_index = p->p1; } else { from_index = p->p1; to_index = p->p0; }
     FL(1); FLD(1);
     double to_theta = eo_asin((from_index / to_index) * eo_sin(from_theta));
-    if (eo_isnan(to_theta)) return 1.0;
+    if (eo_isnan(to_theta)) return R(1.0);
     FL(4 + 4 + 2 + 1); FLD(3);
     double product_1_s = from_index * eo_cos(from_theta);
     double product_2_s = to_index * eo_cos(to_theta);
@@ -1274,14 +1301,14 @@ static double reflection_ratio(tctx *t, const obj *p, const trace_ctx *c) {
     double product_2_p = to_index * eo_cos(from_theta);
     double rs = (product_1_s - product_2_s) / (product_1_s + product_2_s); rs = rs * rs;
     double rp = (product_1_p - product_2_p) / (product_1_p + product_2_p); rp = rp * rp;
-    return (rs + rp) / (1.0 + 1.0);
+    return (rs + rp) / (R(1.0) + R(1.0));
 }
 
 static void reflection_direction(tctx *t, const trace_ctx *c, double *out) {   /* surface.rs:246-256 */
     int D = t->D;
     double d = v_dot(D, c->intersection.direction, c->normal_closer);
     FL(3 * D);
-    for (int i = 0; i < D; i++) out[i] = c->normal_closer[i] * -2.0 * d + c->intersection.direction[i];
+    for (int i = 0; i < D; i++) out[i] = c->normal_closer[i] * -R(2.0) * d + c->intersection.direction[i];
 }
 
 static void threshold_direction(tctx *t, const obj *p, const trace_ctx *c, double *out) {
@@ -1293,7 +1320,7 @@ static void threshold_direction(tctx *t, const obj *p, const trace_ctx *c, doubl
     double from_theta = angle_between(D, c->intersection.direction, normal);
     if (!c->exiting) FLD(1);
     FL(2);
-    double modifier = c->exiting ? p->p0 : 1.0 / p->p0;
+    double modifier = c->exiting ? p->p0 : R(1.0) / p->p0;
     double to_theta = eo_asin(modifier * eo_sin(from_theta));
     double angle_delta = to_theta - from_theta;
     general_rotation(D, normal, c->intersection.direction, angle_delta, out);
@@ -1323,17 +1350,17 @@ static rgba_t surface_color(tctx *t, const obj *p, const trace_ctx *c) {
         v_neg(D, p->dir, nl);
         double angle = angle_between(D, normal, nl);
         FL(1); FLD(1);
-        double ratio = 1.0 - angle / EO_PI_C;
+        double ratio = R(1.0) - angle / EO_PI_C;
         return combine_palette_color(p->c1, p->c0, ratio);
     }
     case COL_PERLIN: {                                                      /* d3/entity/surface.rs:22-40 */
-        double time_millis = (double)t->time_ms / 1000.0;
+        double time_millis = (double)t->time_ms / R(1000.0);
         const double *l = c->intersection.location;
         FL(2); FLD(4);
         double value = perlin4(p->perm, l[0] / p->p0, l[1] / p->p0, l[2] / p->p0, time_millis * p->p1);
         rgba_t o;
-        hsv_to_rgb(value * 360.0, 1.0, 1.0, &o.r, &o.g, &o.b);
-        o.a = 1.0;
+        hsv_to_rgb(value * R(360.0), R(1.0), R(1.0), &o.r, &o.g, &o.b);
+        o.a = R(1.0);
         return o;
     }
     default: return mapped_get_color(t, p->o0, c->intersection.location);   /* surface.rs:536-542 */
@@ -1353,7 +1380,7 @@ static int trace_closest(tctx *t, const obj *belongs_to, const double *loc, cons
     const eo_scene *s = t->scene;
     int D = t->D;
     int have = 0;
-    double closest_distance = 0.0;
+    double closest_distance = R(0.0);
     for (int e = 0; e < s->n_entities; e++) {
         const obj *other = s->entities[e];
         if (!other->o2) continue;                          /* filter: surface().is_some() (universe/mod.rs:158-160) */
@@ -1385,12 +1412,12 @@ static int trace_closest(tctx *t, const obj *belongs_to, const double *loc, cons
 static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c, uint32_t depth_remaining) {
     int D = t->D;
     double ratio = reflection_ratio(t, surface->o0, c);
-    ratio = rust_max(rust_min(ratio, 1.0), 0.0);
+    ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));
 
     int have_inter = 0, have_refl = 0;
     rgba_t inter = {0, 0, 0, 0}, refl = {0, 0, 0, 0};
 
-    if (!(ratio >= 1.0)) {                                                  /* get_intersection_color */
+    if (!(ratio >= R(1.0))) {                                                  /* get_intersection_color */
         rgba_t sc = surface_color(t, surface->o3, c);
         uint8_t px[4];
         to_pixel4(t, sc, px);
@@ -1399,7 +1426,7 @@ static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c,
             double tdir[MAXD], new_origin[MAXD];
             threshold_direction(t, surface->o2, c, tdir);
             FL(3 * D);
-            for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + -c->normal_closer[i] * EO_EPS128_A * 128.0;
+            for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + -c->normal_closer[i] * EO_EPS128_A * R(128.0);
             const obj *dest = c->exiting ? material_at(t, new_origin) : c->intersection_traceable;
             if (dest) {
                 material_exit(t, c->origin_traceable->o1, tdir);
@@ -1412,11 +1439,11 @@ static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c,
             }
         }
     }
-    if (!(ratio <= 0.0)) {                                                  /* get_reflection_color */
+    if (!(ratio <= R(0.0))) {                                                  /* get_reflection_color */
         double rdir[MAXD], new_origin[MAXD];
         reflection_direction(t, c, rdir);
         FL(3 * D);
-        for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + c->normal_closer[i] * EO_EPS128_A * 128.0;
+        for (int i = 0; i < D; i++) new_origin[i] = c->intersection.location[i] + c->normal_closer[i] * EO_EPS128_A * R(128.0);
         refl = trace(t, depth_remaining - 1, c->origin_traceable, new_origin, rdir, NULL);
         have_refl = 1;
     }
@@ -1430,7 +1457,7 @@ static rgba_t surface_get_color(tctx *t, const obj *surface, const trace_ctx *c,
 
 static rgba_t trace(tctx *t, uint32_t max_depth, const obj *belongs_to, const double *loc, const double *dir, double *first_hit_t) {   /* universe/mod.rs:149-184 */
     int D = t->D;
-    if (first_hit_t) *first_hit_t = -1.0;
+    if (first_hit_t) *first_hit_t = -R(1.0);
     if (max_depth > 0) {
         t->stats.rays++;
         trace_ctx c;
@@ -1442,7 +1469,7 @@ static rgba_t trace(tctx *t, uint32_t max_depth, const obj *belongs_to, const do
     t->stats.bg_samples++;
     double pt[MAXD];
     FL(D);
-    for (int i = 0; i < D; i++) pt[i] = 0.0 + dir[i];                       /* direction.to_point(), util.rs:616-618 */
+    for (int i = 0; i < D; i++) pt[i] = R(0.0) + dir[i];                       /* direction.to_point(), util.rs:616-618 */
     return mapped_get_color(t, t->scene->background, pt);
 }
 
@@ -1457,10 +1484,10 @@ static int trace_path(tctx *t, double distance, const obj *belongs_to, const dou
     if (level > EO_PATH_MAX_STEPS) { t->stats.errors++; return -1; }
     trace_ctx c;
     if (trace_closest(t, belongs_to, loc, dir, &c)) {                         /* filter: surface().is_some(), mod.rs:194-196 */
-        if (!(distance - c.intersection.distance <= 0.0)) {                   /* surface.rs:165-167 */
+        if (!(distance - c.intersection.distance <= R(0.0))) {                   /* surface.rs:165-167 */
             double new_distance = distance - c.intersection.distance;
             double new_origin[MAXD], tdir[MAXD];
-            for (int i = 0; i < D; i++) new_origin[i] = c.intersection.location[i] + -c.normal_closer[i] * EO_EPS128_A * 128.0;
+            for (int i = 0; i < D; i++) new_origin[i] = c.intersection.location[i] + -c.normal_closer[i] * EO_EPS128_A * R(128.0);
             const obj *dest = c.exiting ? material_at(t, new_origin) : c.intersection_traceable;   /* surface.rs:177-185 */
             if (dest) {
                 v_copy(D, c.intersection.direction, tdir);
@@ -1501,10 +1528,10 @@ int eo_trace_path_unknown(const eo_scene *s, const double *loc, const double *di
 typedef struct { double w, i, j, k; } quat_t;
 static quat_t quat_from_axisangle(const double *aa) {
     double sqang = v_nsq(3, aa);
-    quat_t q = { 1.0, 0.0, 0.0, 0.0 };
-    if (sqang == 0.0) return q;
+    quat_t q = { R(1.0), R(0.0), R(0.0), R(0.0) };
+    if (sqang == R(0.0)) return q;
     double ang = sqrt(sqang);
-    double s = eo_sin(ang / 2.0), c = eo_cos(ang / 2.0);
+    double s = eo_sin(ang / R(2.0)), c = eo_cos(ang / R(2.0));
     double s_ang = s / ang;
     q.w = c; q.i = aa[0] * s_ang; q.j = aa[1] * s_ang; q.k = aa[2] * s_ang;
     return q;
@@ -1512,7 +1539,7 @@ static quat_t quat_from_axisangle(const double *aa) {
 static void quat_rotate(quat_t q, const double *v, double *out) {
     double qv[3] = { q.i, q.j, q.k }, t[3], u[3];
     v_cross3(qv, v, t);
-    t[0] = t[0] * 2.0; t[1] = t[1] * 2.0; t[2] = t[2] * 2.0;
+    t[0] = t[0] * R(2.0); t[1] = t[1] * R(2.0); t[2] = t[2] * R(2.0);
     v_cross3(qv, t, u);
     for (int a = 0; a < 3; a++) out[a] = (t[a] * q.w + u[a]) + v[a];
 }
@@ -1533,7 +1560,7 @@ static int approx_eq_ulps(double a, double b, uint32_t ulps) {
     return d < (int64_t)ulps;
 }
 static void rotate_pitch_static(double *forward, double *up, double angle, int snap) {   /* d3/entity/camera.rs:116-137 */
-    static const double Z[3] = { 0.0, 0.0, 1.0 };
+    static const double Z[3] = { R(0.0), R(0.0), R(1.0) };
     double axis_h[3];
     v_cross3(forward, up, axis_h); normalize_mut(3, axis_h);
     if (snap) {
@@ -1542,7 +1569,7 @@ static void rotate_pitch_static(double *forward, double *up, double angle, int s
         if (result_angle < angle) to_pole = 1;
         else if (EO_PI_C - result_angle < -angle) to_pole = -1;
         if (to_pole) {
-            forward[0] = to_pole > 0 ? 0.0 : -0.0; forward[1] = forward[0]; forward[2] = to_pole > 0 ? 1.0 : -1.0;
+            forward[0] = to_pole > 0 ? R(0.0) : -R(0.0); forward[1] = forward[0]; forward[2] = to_pole > 0 ? R(1.0) : -R(1.0);
             v_cross3(axis_h, forward, up); normalize_mut(3, up);
             return;
         }
@@ -1571,15 +1598,15 @@ static void mat4_mul_vec(double m[4][4], const double *v, double *out) {   /* m[
 int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_input *in) {
     eo_camera cam = *camera;
     int D = cam.dim;
-    double sens = in->mouse_sensitivity != 0.0 ? in->mouse_sensitivity : 0.01;
-    double speed = in->speed != 0.0 ? in->speed : 10.0;
-    double delta_millis = (double)in->delta_time_ms / 1000.0;
+    double sens = in->mouse_sensitivity != R(0.0) ? in->mouse_sensitivity : R(0.01);
+    double speed = in->speed != R(0.0) ? in->speed : R(10.0);
+    double delta_millis = (double)in->delta_time_ms / R(1000.0);
     double mx = (double)in->delta_mouse_x, my = (double)in->delta_mouse_y;
     uint32_t keys = in->keys;
-    double direction[MAXD] = { 0.0, 0.0, 0.0, 0.0 };
-    static const double Z[3] = { 0.0, 0.0, 1.0 };
+    double direction[MAXD] = { R(0.0), R(0.0), R(0.0), R(0.0) };
+    static const double Z[3] = { R(0.0), R(0.0), R(1.0) };
     if (D == 3 && kind == EO_CAMERA_PITCH_YAW_3) {
-        if (!(mx * mx + my * my <= 0.0)) {                                   /* update_rotation :94-108 */
+        if (!(mx * mx + my * my <= R(0.0))) {                                   /* update_rotation :94-108 */
             double dir2[2] = { mx * sens, my * sens };
             rotate_axis_angle(Z, -dir2[0], cam.forward); normalize_mut(3, cam.forward);     /* rotate_yaw_static :110-114 */
             rotate_axis_angle(Z, -dir2[0], cam.up); normalize_mut(3, cam.up);
@@ -1587,23 +1614,23 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
         }
     } else if (D == 3) {                                                     /* FreeCamera3::update_rotation :299-324 */
         double dir2[2] = { mx * sens, my * sens };
-        double roll = 0.0;
-        if (keys & EO_KEY_Q) roll -= 1.0;
-        if (keys & EO_KEY_E) roll += 1.0;
-        roll *= delta_millis * 2.0;
-        if (dir2[0] != 0.0) { rotate_axis_angle(cam.up, -dir2[0], cam.forward); normalize_mut(3, cam.forward); }
-        if (dir2[1] != 0.0) rotate_pitch_static(cam.forward, cam.up, -dir2[1], 0);
-        if (roll != 0.0) { rotate_axis_angle(cam.forward, roll, cam.up); normalize_mut(3, cam.up); }
+        double roll = R(0.0);
+        if (keys & EO_KEY_Q) roll -= R(1.0);
+        if (keys & EO_KEY_E) roll += R(1.0);
+        roll *= delta_millis * R(2.0);
+        if (dir2[0] != R(0.0)) { rotate_axis_angle(cam.up, -dir2[0], cam.forward); normalize_mut(3, cam.forward); }
+        if (dir2[1] != R(0.0)) rotate_pitch_static(cam.forward, cam.up, -dir2[1], 0);
+        if (roll != R(0.0)) { rotate_axis_angle(cam.forward, roll, cam.up); normalize_mut(3, cam.up); }
     } else {                                                                 /* FreeCamera4::update_rotation d4:68-126 */
-        double angle = 0.0;
-        if (keys & EO_KEY_C) angle += 1.0;
-        if (keys & EO_KEY_M) angle -= 1.0;
-        if (angle != 0.0) {
-            angle *= delta_millis * 2.0;
+        double angle = R(0.0);
+        if (keys & EO_KEY_C) angle += R(1.0);
+        if (keys & EO_KEY_M) angle -= R(1.0);
+        if (angle != R(0.0)) {
+            angle *= delta_millis * R(2.0);
             int ax[4] = { !!(keys & EO_KEY_I), !!(keys & EO_KEY_O), !!(keys & EO_KEY_K), !!(keys & EO_KEY_L) };
             if (ax[0] + ax[1] + ax[2] + ax[3] == 2) {
                 double storage[16];                                          /* column-major: storage[col*4 + row] */
-                for (int idx = 0; idx < 16; idx++) storage[idx] = (idx / 4 == idx % 4) ? 1.0 : 0.0;
+                for (int idx = 0; idx < 16; idx++) storage[idx] = (idx / 4 == idx % 4) ? R(1.0) : R(0.0);
                 for (int idx = 0; idx < 16; idx++) {
                     int row = idx / 4, column = idx % 4;                     /* the reference's names for them */
                     if (ax[row] && ax[column]) storage[idx] = row == column ? eo_cos(angle) : (row < column ? -eo_sin(angle) : eo_sin(angle));
@@ -1626,7 +1653,7 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
         }
     }
     double distance = speed * delta_millis;
-    if (distance == 0.0) { *camera = cam; return 0; }
+    if (distance == R(0.0)) { *camera = cam; return 0; }
     double left[MAXD], vertical[MAXD], ana[4] = { 0, 0, 0, 0 };
     if (D == 3) {
         v_cross3(cam.up, cam.forward, left); normalize_mut(3, left);         /* get_left :60-62 */
@@ -1643,7 +1670,7 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
     if (keys & EO_KEY_LCONTROL) v_sub(D, direction, vertical, direction);
     if (D == 4 && (keys & EO_KEY_Q)) v_add(D, direction, ana, direction);
     if (D == 4 && (keys & EO_KEY_E)) v_sub(D, direction, ana, direction);
-    if (v_nsq(D, direction) != 0.0) {
+    if (v_nsq(D, direction) != R(0.0)) {
         distance *= v_norm(D, direction);
         normalize_mut(D, direction);
         double nl[MAXD], nd[MAXD];
@@ -1652,7 +1679,7 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
         if (rc == 1) {
             double rotation_scale = angle_between(D, direction, nd);
             if (D == 3) {
-                if (!approx_eq_ulps(rotation_scale, 0.0, 8)) {               /* d3 camera.rs:230-239 */
+                if (!approx_eq_ulps(rotation_scale, R(0.0), 8)) {               /* d3 camera.rs:230-239 */
                     double axis[3], aa[3], r[3];
                     v_cross3(direction, nd, axis);
                     v_scale(3, axis, rotation_scale, aa);
@@ -1660,7 +1687,7 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
                     quat_rotate(q, cam.forward, r); v_copy(3, r, cam.forward);
                     quat_rotate(q, cam.up, r); v_copy(3, r, cam.up);
                 }
-            } else if (!approx_eq_ulps(rotation_scale, 0.0, 4 * 8)) return 1;   /* unimplemented!() */
+            } else if (!approx_eq_ulps(rotation_scale, R(0.0), 4 * 8)) return 1;   /* unimplemented!() */
             v_copy(D, nl, cam.location);
         }
     }
@@ -1671,15 +1698,15 @@ int eo_camera_update(const eo_scene *s, int kind, eo_camera *camera, const eo_in
 /* camera ray: d3/entity/camera.rs:155-185 (identical in FreeCamera3 :360-390), d4/entity/camera.rs:146-176 */
 static void camera_ray(const eo_camera *cam, int sx, int sy, int sw, int sh, double *point, double *vector) {
     int D = cam->dim;
-    double rel_x = (double)(sx - sw / 2) + (double)(1 - sw % 2) / 2.0;
-    double rel_y = (double)(sy - sh / 2) + (double)(1 - sh % 2) / 2.0;
+    double rel_x = (double)(sx - sw / 2) + (double)(1 - sw % 2) / R(2.0);
+    double rel_y = (double)(sy - sh / 2) + (double)(1 - sh % 2) / R(2.0);
     double w = (double)sw, h = (double)sh;
     double right[MAXD];
     if (D == 3) { double cr[MAXD]; v_cross3(cam->forward, cam->up, cr); v_normalize(3, cr, right); }
     else v_neg(D, cam->left, right);
     FL(2 + 1 + 3 + 1 + 6 * D); FLD(2 + 2 + 2);
-    double fov_rad = EO_PI_C * (double)cam->fov_deg / 180.0;
-    double dist = sqrt(w * w + h * h) / (2.0 * eo_tan(fov_rad / 2.0));
+    double fov_rad = EO_PI_C * (double)cam->fov_deg / R(180.0);
+    double dist = sqrt(w * w + h * h) / (R(2.0) * eo_tan(fov_rad / R(2.0)));
     double p[MAXD];
     for (int i = 0; i < D; i++) {
         double center = cam->location[i] + cam->forward[i] * dist;
@@ -1697,15 +1724,15 @@ static void trace_screen_point(tctx *t, const eo_camera *cam, int x, int y, int 
     camera_ray(cam, x, y, w, h, point, vector);
     const obj *belongs_to = material_at(t, point);
     if (!belongs_to) {
-        if (hit) *hit = -1.0;
-        if ((x / 8 + y / 8) % 2 == 0) { rgb[0] = 0.0; rgb[1] = 0.0; rgb[2] = 0.0; }
-        else { rgb[0] = 1.0; rgb[1] = 0.0; rgb[2] = 1.0; }
+        if (hit) *hit = -R(1.0);
+        if ((x / 8 + y / 8) % 2 == 0) { rgb[0] = R(0.0); rgb[1] = R(0.0); rgb[2] = R(0.0); }
+        else { rgb[0] = R(1.0); rgb[1] = R(0.0); rgb[2] = R(1.0); }
         return;
     }
     double dir[MAXD];
     v_copy(t->D, vector, dir);
     material_enter(t, belongs_to->o1, dir);
-    rgba_t white = { 1.0, 1.0, 1.0, 1.0 };
+    rgba_t white = { R(1.0), R(1.0), R(1.0), R(1.0) };
     pre_t background = into_premultiplied(white);
     pre_t foreground = into_premultiplied(trace(t, cam->max_depth, belongs_to, point, dir, hit));
     rgba_t out = from_premultiplied(blend_pre(BL_OVER, foreground, background));
@@ -1731,10 +1758,10 @@ static void *worker(void *arg) {
         if (y >= j->frame->row_end) break;
         for (uint32_t x = 0; x < W; x++) {
             size_t idx = (size_t)(y - j->frame->row_begin) * W + x;
-            double rgb[3], hit = -1.0;
+            double rgb[3], hit = -R(1.0);
             int surrounding = j->frame->debug_crosshair &&
                 ((x == hw && (y == hh - 1 || y == hh + 1)) || (y == hh && (x == hw - 1 || x == hw + 1)));
-            if (surrounding) { rgb[0] = 1.0; rgb[1] = 0.0; rgb[2] = 0.0; }   /* Rgb::new_u8(255,0,0) */
+            if (surrounding) { rgb[0] = R(1.0); rgb[1] = R(0.0); rgb[2] = R(0.0); }   /* Rgb::new_u8(255,0,0) */
             else trace_screen_point(&t, j->cam, (int)x, (int)y, (int)W, (int)H, rgb, &hit);
             j->rgb[idx * 3 + 0] = to_u8(&t, rgb[0]);
             j->rgb[idx * 3 + 1] = to_u8(&t, rgb[1]);
