@@ -9,6 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EU_LIB_PATH") or os.path.join(HERE, "libeuclider_amd.so")    # EU_LIB_PATH: A/B builds (diagnostics)
+LIB_PATH_F32 = os.path.join(HERE, "libeuclider_amd_f32.so")      # F = f32: the reference's `low_precision` cargo feature is a second binary
 
 EU_OK = 0
 EU_ERR_INVALID_ARGUMENT = -1
@@ -108,6 +109,7 @@ SYMBOLS = {
 }
 
 _lib = None
+_lib_f32 = None
 
 
 def _share_hip_runtime_with_torch():
@@ -129,8 +131,21 @@ def _share_hip_runtime_with_torch():
         pass
 
 
-def lib():
-    global _lib
+def lib(low_precision=False):
+    """The product library; low_precision=True: the F = f32 build (same ABI: poses, hit distances and colours stay f64 at the boundary)."""
+    global _lib, _lib_f32
+    if low_precision:
+        if _lib_f32 is None:
+            if not os.path.exists(LIB_PATH_F32):
+                raise ImportError("%s is missing: build it with `make -C euclider_amd/csrc`" % LIB_PATH_F32)
+            _share_hip_runtime_with_torch()
+            L = C.CDLL(LIB_PATH_F32)
+            for name, (res, args) in SYMBOLS.items():
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
+            _lib_f32 = L
+        return _lib_f32
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C euclider_amd/csrc` (or __graft_entry__.build()); "

@@ -337,5 +337,14 @@ EU_HD static inline double eu_atan2(double y, double x) {
     }
 }
 
+/* f64 entry points under names eu_real.h does not touch (it makes eu_acos(x) etc. round to the path's F at once): the
+ * LinearSpace expressions are evaluated in f64 whatever F is */
+EU_HD inline double eu_sin_f64(double x) { return eu_sin(x); }
+EU_HD inline double eu_cos_f64(double x) { return eu_cos(x); }
+EU_HD inline double eu_tan_f64(double x) { return eu_tan(x); }
+EU_HD inline double eu_asin_f64(double x) { return eu_asin(x); }
+EU_HD inline double eu_acos_f64(double x) { return eu_acos(x); }
+EU_HD inline double eu_atan_f64(double x) { return eu_atan(x); }
+EU_HD inline double eu_atan2_f64(double y, double x) { return eu_atan2(y, x); }
 
 #endif /* EU_MATH_H */

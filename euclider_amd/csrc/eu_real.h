@@ -26,4 +26,14 @@ typedef double eu_f64;
 #define EU_REAL_BITS 64
 #endif
 
+/* the elementary functions are evaluated in f64 (eu_math.h) and rounded to F at once, so that no expression continues in double
+ * behind a call (in the default build the casts are no-ops); eu_*_f64 are the untouched entry points */
+#define eu_acos(x) ((double)eu_acos(x))
+#define eu_asin(x) ((double)eu_asin(x))
+#define eu_sin(x) ((double)eu_sin(x))
+#define eu_cos(x) ((double)eu_cos(x))
+#define eu_tan(x) ((double)eu_tan(x))
+#define eu_atan(x) ((double)eu_atan(x))
+#define eu_atan2(y, x) ((double)eu_atan2(y, x))
+
 #endif

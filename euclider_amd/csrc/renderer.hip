@@ -51,21 +51,21 @@ __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *_
     }
 }
 
-__global__ void eu_math_kernel(int fn, const double *x, const double *y, double *out, size_t n) {
+__global__ void eu_math_kernel(int fn, const eu_f64 *x, const eu_f64 *y, eu_f64 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double a = x[i], b = y ? y[i] : R(0.0), r;
+    eu_f64 a = x[i], b = y ? y[i] : 0.0, r;
     switch (fn) {
-    case 0: r = eu_acos(a); break;
-    case 1: r = eu_asin(a); break;
-    case 2: r = eu_sin(a); break;
-    case 3: r = eu_cos(a); break;
-    case 4: r = eu_tan(a); break;
-    case 5: r = eu_atan2(a, b); break;
-    case 6: r = sqrt(a); break;
+    case 0: r = eu_acos_f64(a); break;
+    case 1: r = eu_asin_f64(a); break;
+    case 2: r = eu_sin_f64(a); break;
+    case 3: r = eu_cos_f64(a); break;
+    case 4: r = eu_tan_f64(a); break;
+    case 5: r = eu_atan2_f64(a, b); break;
+    case 6: r = sqrt((eu_f64)a); break;
     case 7: r = a / b; break;
-    case 8: r = fmod(a, b); break;
-    default: r = R(0.0);
+    case 8: r = fmod((eu_f64)a, (eu_f64)b); break;
+    default: r = 0.0;
     }
     out[i] = r;
 }
@@ -115,6 +115,7 @@ struct eu_renderer {
     size_t wf_pixels = 0;
     uint32_t wf_depth = 0;                   /* deepest max_depth the node slots are sized for */
     int wf_sets = 0;                         /* buffer sets allocated */
+    bool prepare_only = false;               /* render_device_impl: size the work buffers for the frame, launch nothing */
     /* FINISH step: once a generation holds fewer than wf_finish_rays rays, the stream kernel (trace_stream.h, import mode) takes
      * that generation's queue over and finishes those rays and all their descendants in ONE launch; the generation to hand over at
      * is learnt from the previous frame's queue lengths (read back asynchronously), so a wrong guess costs time, never correctness */
@@ -224,6 +225,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
         HIP_TRY(hipMemset(r->d_counters, 0, sizeof(EuDevCounters)));
+        HIP_TRY(hipDeviceSynchronize());      /* (hipMemset is asynchronous to the host; see wf_ensure) */
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
         return EU_OK;
@@ -327,9 +329,11 @@ static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth, int n_se
     const size_t ray_cap = seg_cap * n_seg;
     const size_t node_cap = ray_cap * (size_t)(r->wf_depth ? r->wf_depth : 1u);      /* one slot per ray of every generation the deepest frame so far has */
     if (ray_cap > 0x7ffffff0ull || node_cap > 0xfffffff0ull) { r->err = "frame too large for 32-bit queue indices; render it in row tiles"; return EU_ERR_CAPACITY; }
+    static const bool poison = getenv("EU_DEBUG_POISON") != nullptr;      /* diagnostics: no buffer may rely on fresh memory being zero */
     auto alloc = [&](void **p, size_t bytes) -> int {
         HIP_TRY(hipMalloc(p, bytes));
         r->wf_allocs.push_back(*p);
+        if (poison) { HIP_TRY(hipMemset(*p, 0xAB, bytes)); HIP_TRY(hipDeviceSynchronize()); }
         return EU_OK;
     };
     int rc;
@@ -356,6 +360,10 @@ static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth, int n_se
     if ((rc = alloc((void **)&B.node_kind, node_cap))) return rc;
     if ((rc = alloc((void **)&B.seg_count, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4))) return rc;
     HIP_TRY(hipMemset(B.seg_count, 0, (size_t)(EU_MAX_DEPTH + 2) * n_seg * 4));
+    /* hipMemset on device memory is asynchronous to the host and ordered on the NULL stream only, which the (non-blocking) trace
+     * streams do not synchronise with: without this wait the clear can land after the first frame's gen kernel has published its
+     * queue lengths (seen as whole strips of unwritten pixels, first frame of a fresh renderer, only with several hardware queues) */
+    HIP_TRY(hipDeviceSynchronize());
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
     if (r->wf_finish_rays) {
@@ -464,6 +472,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     const size_t band_pixels = (size_t)band_rows * df_in.width;
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, dc.max_depth, two_streams ? r->wf_n_streams : 1);
     if (rc != EU_OK) return rc;
+    if (r->prepare_only) return EU_OK;      /* buffers, streams and events exist now: nothing is allocated while the frame is in flight */
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     if (r->dbg_hs_cap) hs_cap = r->dbg_hs_cap;      /* diagnostics only */
     const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
@@ -654,6 +663,11 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     df.time_s = (double)f->time_ms / R(1000.0);
     if (single) { df.strip_count = 0; df.local_rows = 1; df.single_pixel = 1; df.single_x = single_x; df.single_y = f->row_begin; df.tiles_x = 1; df.n_tiles = 1; }
     if (rows == 0) return EU_OK;
+    if (r->prepare_only) {
+        if (r->path == eu_renderer::PATH_WAVEFRONT && r->use_wavefront)
+            return (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
+        return EU_OK;
+    }
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, sizeof(EuDevCounters), stream));
     const int slot = (int)(r->launches % eu_renderer::EV_RING);
     HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
@@ -837,7 +851,7 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
     return EU_OK;
 }
 
-extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const eu_frame *f, int32_t x, int32_t y, double rgb[3]) {
+extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const eu_frame *f, int32_t x, int32_t y, eu_f64 rgb[3]) {
     if (!r || !cam || !f || !rgb) return EU_ERR_INVALID_ARGUMENT;
     if (x < 0 || y < 0 || (uint32_t)x >= f->width || (uint32_t)y >= f->height) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
@@ -1119,14 +1133,29 @@ extern "C" int eu_render_multi(eu_multi *m, const eu_camera *cam, const eu_frame
             m->cap_pixels[k] = pixels;
         }
     }
-    /* trace + pack everywhere, then one transfer per device into its slot of the root's buffer */
+    /* every renderer's work buffers, streams and events first: no allocation (which may synchronise or clear memory) happens
+     * once the first device's kernels are in flight */
+    for (uint32_t k = 0; k < n; k++) {
+        if (lrows[k] == 0) continue;
+        MULTI_TRY(hipSetDevice(m->devices[k]));
+        m->r[k]->prepare_only = true;
+        const int prc = render_device_impl(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, nullptr);
+        m->r[k]->prepare_only = false;
+        if (prc != EU_OK) { m->err = m->r[k]->err; return prc; }
+    }
+    /* trace everywhere ... */
     for (uint32_t k = 0; k < n; k++) {
         if (lrows[k] == 0) continue;
         MULTI_TRY(hipSetDevice(m->devices[k]));
         int rc = render_device_impl(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, nullptr);
         if (rc != EU_OK) { m->err = m->r[k]->err; return rc; }
+    }
+    /* ... then pack, and one transfer per device into its slot of the root's buffer */
+    for (uint32_t k = 0; k < n; k++) {
+        if (lrows[k] == 0) continue;
+        MULTI_TRY(hipSetDevice(m->devices[k]));
         uint8_t *packed = k == 0 ? m->d_gathered : m->d_rgb[k];      /* the root packs straight into slot 0 */
-        rc = eu_pack_rgb_device(m->r[k], m->d_rgba[k], packed, (size_t)lrows[k] * W, m->stream[k]);
+        int rc = eu_pack_rgb_device(m->r[k], m->d_rgba[k], packed, (size_t)lrows[k] * W, m->stream[k]);
         if (rc != EU_OK) { m->err = m->r[k]->err; return rc; }
         if (k > 0) MULTI_TRY(hipMemcpyPeerAsync(m->d_gathered + (size_t)k * dev_stride, m->devices[0], packed, m->devices[k], (size_t)lrows[k] * row_bytes, m->stream[k]));
         MULTI_TRY(hipEventRecord(m->sent[k], m->stream[k]));
@@ -1156,8 +1185,8 @@ extern "C" int eu_render_multi(eu_multi *m, const eu_camera *cam, const eu_frame
 extern "C" const char *eu_multi_error(const eu_multi *m) { return m ? m->err.c_str() : ""; }
 
 /* Universe::trace_path_unknown (universe/mod.rs:273-286) on the resident scene: one lane, synchronous. */
-extern "C" int eu_trace_path(eu_renderer *r, const double location[4], const double direction[4], double distance,
-                             double out_location[4], double out_direction[4], int32_t *found) {
+extern "C" int eu_trace_path(eu_renderer *r, const eu_f64 location[4], const eu_f64 direction[4], eu_f64 distance,
+                             eu_f64 out_location[4], eu_f64 out_direction[4], int32_t *found) {
     if (!r || !location || !direction || !out_location || !out_direction || !found) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     if (r->hit_cap > 96) { r->err = "scene needs a deeper hit stack than the path kernel has (96)"; return EU_ERR_CAPACITY; }
@@ -1187,8 +1216,8 @@ extern "C" int eu_camera_update(eu_renderer *r, eu_camera *cam, const eu_input *
     if (!cam || !in) return EU_ERR_INVALID_ARGUMENT;
     if (r && cam->dim != r->dim) { r->err = "camera dimension does not match the scene"; return EU_ERR_INVALID_ARGUMENT; }
     euclider::TracePathFn fn;
-    if (r) fn = [r](const double *loc, const double *dir, double dist, double *ol, double *od) -> int {
-        double l4[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0};
+    if (r) fn = [r](const eu_f64 *loc, const eu_f64 *dir, eu_f64 dist, eu_f64 *ol, eu_f64 *od) -> int {
+        eu_f64 l4[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0};
         for (int k = 0; k < r->dim; k++) { l4[k] = loc[k]; d4[k] = dir[k]; }
         int32_t found = 0;
         const int rc = eu_trace_path(r, l4, d4, dist, ol, od, &found);
@@ -1197,12 +1226,12 @@ extern "C" int eu_camera_update(eu_renderer *r, eu_camera *cam, const eu_input *
     return euclider::camera_update(cam, in, fn);
 }
 
-extern "C" int eu_selftest_math(int device, int fn, const double *x, const double *y, double *out, size_t n) {
+extern "C" int eu_selftest_math(int device, int fn, const eu_f64 *x, const eu_f64 *y, eu_f64 *out, size_t n) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device < 0 || device >= cnt) return EU_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return EU_ERR_HIP;
     if (n == 0) return EU_OK;
-    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    eu_f64 *dx = nullptr, *dy = nullptr, *dout = nullptr;
     int rc = EU_ERR_HIP;
     if (hipMalloc((void **)&dx, n * 8) == hipSuccess && hipMalloc((void **)&dout, n * 8) == hipSuccess && (!y || hipMalloc((void **)&dy, n * 8) == hipSuccess)) {
         if (hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice) == hipSuccess && (!y || hipMemcpy(dy, y, n * 8, hipMemcpyHostToDevice) == hipSuccess)) {

@@ -12,6 +12,19 @@
 
 #include "eu_math.h"
 
+/* Margins of the bounding spheres used for exact culling (trace_device.h, ray_misses_bound): the enlargement has to dwarf the
+ * rounding of the device's test, so it depends on F.  f64: 1e-6 relative (rounding ~1e-15); f32: 1e-3 relative (rounding ~1e-6), and
+ * the discriminant form of the test only within 10 radii instead of 10^4 (its cancellation error grows with the square of the distance). */
+#if EU_REAL_BITS == 32
+#define EU_BOUND_REL R(1.0e-3)
+#define EU_BOUND_ABS R(1.0e-5)
+#define EU_BOUND_FAR2 R(1.0e2)
+#else
+#define EU_BOUND_REL R(1.0e-6)
+#define EU_BOUND_ABS R(1.0e-9)
+#define EU_BOUND_FAR2 R(1.0e8)
+#endif
+
 namespace euclider {
 
 /* ------------------------------------------------------------------ errors */
@@ -778,10 +791,10 @@ struct Flattener {
                 double cmax = R(0.0);
                 for (int i = 0; i < D; i++) cmax = std::max(cmax, fabs(b.c[i]));
                 const bool ok = b.ok && b.r > R(0.0) && cmax <= R(1.0e6) * b.r;
-                const double rr = b.r * (R(1.0) + R(1.0e-6)) + R(1.0e-9) * std::max(R(1.0), cmax);
+                const double rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
                 for (int i = 0; i < D; i++) params.push_back(ok ? b.c[i] : R(0.0));
                 params.push_back(ok ? rr * rr : -R(1.0));
-                params.push_back(ok ? R(1.0e8) * rr * rr : R(0.0));
+                params.push_back(ok ? EU_BOUND_FAR2 * rr * rr : R(0.0));
             }
             n_leaves += (uint32_t)chain.size();
             len = (uint32_t)chain.size();
@@ -906,11 +919,11 @@ struct Flattener {
         double cmax = R(0.0);
         for (int i = 0; i < D; i++) { if (!std::isfinite(b.c[i])) return 0xffffffffu; cmax = std::max(cmax, fabs(b.c[i])); }
         if (cmax > R(1.0e6) * b.r) return 0xffffffffu;          /* the margin below must dominate rounding of |o - c|^2 */
-        const double rr = b.r * (R(1.0) + R(1.0e-6)) + R(1.0e-9) * std::max(R(1.0), cmax);
+        const double rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
         uint32_t id = (uint32_t)(bounds.size() / (size_t)(D + 2));
         for (int i = 0; i < D; i++) bounds.push_back(b.c[i]);
         bounds.push_back(rr * rr);
-        bounds.push_back(R(1.0e8) * rr * rr);
+        bounds.push_back(EU_BOUND_FAR2 * rr * rr);
         return id;
     }
 

@@ -800,19 +800,19 @@ template <int D> EU_RPN_INLINE eu_f64 eval_rpn(const EuScene &S, uint64_t prog, 
             if (arg == EU_FN_MIN || arg == EU_FN_MAX || arg == EU_FN_ATAN2) { sp--; x = st[(sp - 1) & 7]; }
             eu_f64 r;
             switch (arg) {
-            case EU_FN_SQRT: r = sqrt(x); break;
+            case EU_FN_SQRT: r = sqrt((eu_f64)x); break;
             case EU_FN_ABS: r = fabs(x); break;
             case EU_FN_FLOOR: r = floor(x); break;
             case EU_FN_CEIL: r = ceil(x); break;
             case EU_FN_MIN: r = rpn_min(x, y); break;
             case EU_FN_MAX: r = rpn_max(x, y); break;
-            case EU_FN_SIN: r = eu_sin(x); break;
-            case EU_FN_COS: r = eu_cos(x); break;
-            case EU_FN_TAN: r = eu_tan(x); break;
-            case EU_FN_ASIN: r = eu_asin(x); break;
-            case EU_FN_ACOS: r = eu_acos(x); break;
-            case EU_FN_ATAN: r = eu_atan(x); break;
-            case EU_FN_ATAN2: r = eu_atan2(x, y); break;
+            case EU_FN_SIN: r = eu_sin_f64(x); break;
+            case EU_FN_COS: r = eu_cos_f64(x); break;
+            case EU_FN_TAN: r = eu_tan_f64(x); break;
+            case EU_FN_ASIN: r = eu_asin_f64(x); break;
+            case EU_FN_ACOS: r = eu_acos_f64(x); break;
+            case EU_FN_ATAN: r = eu_atan_f64(x); break;
+            case EU_FN_ATAN2: r = eu_atan2_f64(x, y); break;
             default: r = rpn_signum(x); break;
             }
             st[(sp - 1) & 7] = r;
@@ -827,7 +827,7 @@ template <int D> EU_RPN_INLINE eu_f64 eval_rpn(const EuScene &S, uint64_t prog, 
             case EU_RPN_SUB: r = x - y; break;
             case EU_RPN_MUL: r = x * y; break;
             case EU_RPN_DIV: r = x / y; break;
-            case EU_RPN_REM: r = fmod(x, y); break;
+            case EU_RPN_REM: r = fmod((eu_f64)x, (eu_f64)y); break;
             default: r = pow_int(x, y); break;
             }
             st[(sp - 1) & 7] = r;

@@ -59,7 +59,9 @@ def _duration_to_ms(time):
 
 
 class Environment:
-    def __init__(self, scene_handle, info, camera, substituted_textures):
+    def __init__(self, scene_handle, info, camera, substituted_textures, low_precision=False):
+        self.low_precision = low_precision      # F = f32 (the reference's `low_precision` build): every call goes to that library
+        self._L = _capi.lib(low_precision)
         self._scene = scene_handle
         self.info = info
         self.camera = camera          # mutable pose (the reference mutates it in Camera::update)
@@ -68,7 +70,7 @@ class Environment:
 
     # -- lifetime
     def close(self):
-        L = _capi.lib()
+        L = self._L
         for m in getattr(self, "_multis", {}).values():
             L.eu_multi_destroy(m)
         self._multis = {}
@@ -91,7 +93,7 @@ class Environment:
 
     def renderer(self, device=0):
         if device not in self._renderers:
-            L = _capi.lib()
+            L = self._L
             out = C.c_void_p()
             err = C.create_string_buffer(512)
             rc = L.eu_renderer_create(self._scene, device, C.byref(out), err, len(err))
@@ -114,14 +116,14 @@ class Environment:
 
     @staticmethod
     def local_rows(frame):
-        return _capi.lib().eu_frame_local_rows(C.byref(frame))
+        return _capi.lib().eu_frame_local_rows(C.byref(frame))      # (integer arithmetic: the same in both builds)
 
     def trace_screen_point(self, time, max_depth, screen_x, screen_y, screen_width, screen_height, debug=False, device=0):
         cam = _capi.Camera.from_buffer_copy(self.camera)
         cam.max_depth = max_depth
         fr = self._frame(screen_width, screen_height, _duration_to_ms(time), False)
         rgb = (C.c_double * 3)()
-        rc = _capi.lib().eu_trace_screen_point(self.renderer(device), C.byref(cam), C.byref(fr), screen_x, screen_y, rgb)
+        rc = self._L.eu_trace_screen_point(self.renderer(device), C.byref(cam), C.byref(fr), screen_x, screen_y, rgb)
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return tuple(rgb)
@@ -132,7 +134,7 @@ class Environment:
         loc = (C.c_double * 4)(*([float(x) for x in location] + [0.0] * (4 - D)))
         dr = (C.c_double * 4)(*([float(x) for x in direction] + [0.0] * (4 - D)))
         ol, od, found = (C.c_double * 4)(), (C.c_double * 4)(), C.c_int32(0)
-        rc = _capi.lib().eu_trace_path(self.renderer(device), loc, dr, float(distance), ol, od, C.byref(found))
+        rc = self._L.eu_trace_path(self.renderer(device), loc, dr, float(distance), ol, od, C.byref(found))
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return (tuple(ol)[:D], tuple(od)[:D]) if found.value else None
@@ -144,7 +146,7 @@ class Environment:
         inp = _capi.Input(context.key_mask(), int(context.delta_mouse[0]), int(context.delta_mouse[1]), 0,
                           _duration_to_ms(delta_time), mouse_sensitivity, speed)
         moves = inp.delta_time_ms != 0 and (inp.keys & (0xff if self.dim == 4 else 0x3f)) != 0
-        rc = _capi.lib().eu_camera_update(self.renderer(device) if moves else None, C.byref(self.camera), C.byref(inp))
+        rc = self._L.eu_camera_update(self.renderer(device) if moves else None, C.byref(self.camera), C.byref(inp))
         if rc != _capi.EU_OK:
             raise EuError(rc)
 
@@ -159,7 +161,7 @@ class Environment:
         rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
         hit = np.zeros((nrows, bw), dtype=np.float64) if want_hit_t else None
         st = _capi.Stats()
-        rc = _capi.lib().eu_render(self.renderer(device), C.byref(self.camera), C.byref(fr), rgb.ctypes.data,
+        rc = self._L.eu_render(self.renderer(device), C.byref(self.camera), C.byref(fr), rgb.ctypes.data,
                                    hit.ctypes.data if hit is not None else None, C.byref(st))
         if rc != _capi.EU_OK:
             raise EuError(rc)
@@ -176,7 +178,7 @@ class Environment:
         bw, bh = width // context.resolution, height // context.resolution
         fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, None)
         key = tuple(int(d) for d in devices)
-        L = _capi.lib()
+        L = self._L
         if not hasattr(self, "_multis"):
             self._multis = {}
         if key not in self._multis:
@@ -200,20 +202,20 @@ class Environment:
     def render_device(self, frame, rgba_ptr, hit_t_ptr=None, stream=None, device=0, camera=None):
         """Asynchronous render into caller-owned DEVICE memory (e.g. a torch tensor's data_ptr())."""
         cam = camera if camera is not None else self.camera
-        rc = _capi.lib().eu_render_device(self.renderer(device), C.byref(cam), C.byref(frame), stream, rgba_ptr, hit_t_ptr)
+        rc = self._L.eu_render_device(self.renderer(device), C.byref(cam), C.byref(frame), stream, rgba_ptr, hit_t_ptr)
         if rc != _capi.EU_OK:
             raise EuError(rc)
 
     def stats(self, device=0):
         st = _capi.Stats()
-        rc = _capi.lib().eu_renderer_stats(self.renderer(device), C.byref(st))
+        rc = self._L.eu_renderer_stats(self.renderer(device), C.byref(st))
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
 
     def kernel_ms(self, device=0):
         ms = C.c_float()
-        rc = _capi.lib().eu_renderer_kernel_ms(self.renderer(device), C.byref(ms))
+        rc = self._L.eu_renderer_kernel_ms(self.renderer(device), C.byref(ms))
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return ms.value
@@ -221,13 +223,13 @@ class Environment:
 
     def kernel_ms_history(self, n, device=0):
         buf = (C.c_float * max(1, n))()
-        got = _capi.lib().eu_renderer_kernel_ms_history(self.renderer(device), buf, n)
+        got = self._L.eu_renderer_kernel_ms_history(self.renderer(device), buf, n)
         if got < 0:
             raise EuError(got)
         return [buf[i] for i in range(got)]
 
     def pack_rgb_device(self, rgba_ptr, rgb_ptr, pixels, stream=None, device=0):
-        rc = _capi.lib().eu_pack_rgb_device(self.renderer(device), rgba_ptr, rgb_ptr, pixels, stream)
+        rc = self._L.eu_pack_rgb_device(self.renderer(device), rgba_ptr, rgb_ptr, pixels, stream)
         if rc != _capi.EU_OK:
             raise EuError(rc)
 
@@ -240,7 +242,7 @@ class FrameSequence:
     def __init__(self, env, max_dimensions, slots=2, device=0):
         self.env, self.device = env, device
         self._h = C.c_void_p()
-        rc = _capi.lib().eu_sequence_create(env.renderer(device), int(max_dimensions[0]), int(max_dimensions[1]), int(slots),
+        rc = self.env._L.eu_sequence_create(env.renderer(device), int(max_dimensions[0]), int(max_dimensions[1]), int(slots),
                                             C.byref(self._h))
         if rc != _capi.EU_OK:
             raise EuError(rc)
@@ -250,7 +252,7 @@ class FrameSequence:
         context = context or SimulationContext()
         bw, bh = dimensions[0] // context.resolution, dimensions[1] // context.resolution     # universe/mod.rs:308-309
         fr = self.env._frame(bw, bh, _duration_to_ms(time), context.debugging)
-        rc = _capi.lib().eu_sequence_submit(self._h, C.byref(self.env.camera), C.byref(fr))
+        rc = self.env._L.eu_sequence_submit(self._h, C.byref(self.env.camera), C.byref(fr))
         if rc != _capi.EU_OK:
             raise EuError(rc)
         self.in_flight += 1
@@ -259,7 +261,7 @@ class FrameSequence:
         """RawImage2d of the oldest frame in flight.  With copy=False `.data` aliases a pinned image of the sequence, valid until
         the NEXT call of next() (the sequence rotates slots + 1 images), however many frames are submitted in between."""
         ptr, w, rows, st = C.c_void_p(), C.c_uint32(), C.c_uint32(), _capi.Stats()
-        rc = _capi.lib().eu_sequence_next(self._h, C.byref(ptr), C.byref(w), C.byref(rows), C.byref(st))
+        rc = self.env._L.eu_sequence_next(self._h, C.byref(ptr), C.byref(w), C.byref(rows), C.byref(st))
         if rc != _capi.EU_OK:
             raise EuError(rc)
         self.in_flight -= 1
@@ -271,7 +273,7 @@ class FrameSequence:
 
     def close(self):
         if self._h:
-            _capi.lib().eu_sequence_destroy(self._h)
+            self.env._L.eu_sequence_destroy(self._h)
             self._h = C.c_void_p()
 
     def __enter__(self):
@@ -285,7 +287,8 @@ class Parser:
     """scene::Parser (scene.rs:554-1478).  `texture_dirs`: where relative texture paths are resolved
     (the reference resolves them against the process CWD, scene.rs:1053)."""
 
-    def __init__(self, texture_dirs=None, random_seed=0, texture_overrides=None):
+    def __init__(self, texture_dirs=None, random_seed=0, texture_overrides=None, low_precision=False):
+        self.low_precision = low_precision      # Cargo.toml:18-20 `low_precision`: F = f32
         self.texture_dirs = list(texture_dirs) if texture_dirs is not None else [os.getcwd()]
         self.random_seed = random_seed
         self.texture_overrides = dict(texture_overrides or {})
@@ -295,7 +298,7 @@ class Parser:
         return Parser()
 
     def parse(self, text):
-        L = _capi.lib()
+        L = _capi.lib(self.low_precision)
         keep = []
 
         def loader(user, path, pw, ph, prgba):
@@ -331,7 +334,7 @@ class Parser:
         L.eu_scene_get_info(out, C.byref(info))
         cam = _capi.Camera()
         L.eu_scene_default_camera(out, C.byref(cam))
-        return Environment(out, info, cam, 0)
+        return Environment(out, info, cam, 0, self.low_precision)
 
     def parse_file(self, path):
         with open(path) as f:

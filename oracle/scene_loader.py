@@ -48,8 +48,22 @@ class Intersection(C.Structure):
                 ("normal", C.c_double * 4), ("distance", C.c_double)]
 
 
+class Camera32(C.Structure):
+    """eo_camera of the F = f32 build (libeo_oracle_f32.so: `double` is `float` there, API included)"""
+    _fields_ = [("dim", C.c_int), ("location", C.c_float * 4), ("forward", C.c_float * 4),
+                ("up", C.c_float * 4), ("left", C.c_float * 4), ("fov_deg", C.c_uint32),
+                ("max_depth", C.c_uint32)]
+
+
+def dvec32(vals, n=4):
+    arr = (C.c_float * n)()
+    for i, v in enumerate(vals):
+        arr[i] = float(v)
+    return arr
+
+
 _libs = {}
-VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so"}
+VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so", "f32": "libeo_oracle_f32.so"}
 
 
 def build(force=False, variant=""):
@@ -66,7 +80,9 @@ def lib(variant=""):
         return _libs[variant]
     L = C.CDLL(build(variant=variant))
     _libs[variant] = L
-    dp = C.POINTER(C.c_double)
+    real = C.c_float if variant == "f32" else C.c_double      # F of this build
+    CameraT = Camera32 if variant == "f32" else Camera
+    dp = C.POINTER(real)
     ip = C.POINTER(C.c_int)
     vp = C.c_void_p
 
@@ -79,31 +95,31 @@ def lib(variant=""):
     sig("eo_scene_free", None, vp)
     sig("eo_last_error", C.c_char_p, vp)
     sig("eo_shape_void", C.c_int, vp)
-    sig("eo_shape_sphere", C.c_int, vp, dp, C.c_double)
-    sig("eo_shape_hyperplane", C.c_int, vp, dp, C.c_double)
+    sig("eo_shape_sphere", C.c_int, vp, dp, real)
+    sig("eo_shape_hyperplane", C.c_int, vp, dp, real)
     sig("eo_shape_hyperplane_with_point", C.c_int, vp, dp, dp)
     sig("eo_shape_hyperplane_with_vectors", C.c_int, vp, dp, dp, dp)
-    sig("eo_shape_halfspace", C.c_int, vp, C.c_int, C.c_double)
+    sig("eo_shape_halfspace", C.c_int, vp, C.c_int, real)
     sig("eo_shape_halfspace_with_point", C.c_int, vp, C.c_int, dp)
     sig("eo_shape_cuboid", C.c_int, vp, dp, dp)
-    sig("eo_shape_cylinder", C.c_int, vp, dp, dp, C.c_double)
-    sig("eo_shape_cylinder_with_height", C.c_int, vp, dp, dp, C.c_double, C.c_double)
+    sig("eo_shape_cylinder", C.c_int, vp, dp, dp, real)
+    sig("eo_shape_cylinder_with_height", C.c_int, vp, dp, dp, real, real)
     sig("eo_shape_composable_of", C.c_int, vp, ip, C.c_int, C.c_int)
     sig("eo_material_vacuum", C.c_int, vp)
     sig("eo_transformation_expr", C.c_int, vp, C.c_char_p, C.c_char_p)
     sig("eo_component_transformation", C.c_int, vp, ip, C.c_int)
     sig("eo_material_linear_space", C.c_int, vp, C.c_char_p, ip, C.c_int)
-    sig("eo_reflection_ratio_uniform", C.c_int, vp, C.c_double)
-    sig("eo_reflection_ratio_fresnel", C.c_int, vp, C.c_double, C.c_double)
+    sig("eo_reflection_ratio_uniform", C.c_int, vp, real)
+    sig("eo_reflection_ratio_fresnel", C.c_int, vp, real, real)
     sig("eo_reflection_direction_specular", C.c_int, vp)
     sig("eo_threshold_direction_identity", C.c_int, vp)
-    sig("eo_threshold_direction_snell", C.c_int, vp, C.c_double)
-    sig("eo_blend_function", C.c_int, vp, C.c_char_p, C.c_double)
+    sig("eo_threshold_direction_snell", C.c_int, vp, real)
+    sig("eo_blend_function", C.c_int, vp, C.c_char_p, real)
     sig("eo_color_uniform", C.c_int, vp, dp)
     sig("eo_color_blend", C.c_int, vp, C.c_int, C.c_int, C.c_int)
     sig("eo_color_illumination_global", C.c_int, vp, dp, dp)
     sig("eo_color_illumination_directional", C.c_int, vp, dp, dp, dp)
-    sig("eo_color_perlin_hue", C.c_int, vp, C.c_uint32, C.c_double, C.c_double)
+    sig("eo_color_perlin_hue", C.c_int, vp, C.c_uint32, real, real)
     sig("eo_color_texture", C.c_int, vp, C.c_int)
     sig("eo_uv_sphere", C.c_int, vp, dp)
     sig("eo_uv_derank", C.c_int, vp, C.c_int)
@@ -112,28 +128,28 @@ def lib(variant=""):
     sig("eo_surface_composable", C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int)
     sig("eo_entity", C.c_int, vp, C.c_int, C.c_int, C.c_int)
     sig("eo_entity_void", C.c_int, vp, C.c_int)
-    sig("eo_universe", C.c_int, vp, C.POINTER(Camera), ip, C.c_int, C.c_int)
-    sig("eo_rgba_from_hsva", None, C.c_double, C.c_double, C.c_double, C.c_double, dp)
-    sig("eo_default_camera", C.c_int, C.c_int, dp, C.POINTER(Camera))
-    sig("eo_scene_camera", C.c_int, vp, C.POINTER(Camera))
-    sig("eo_render", C.c_int, vp, C.POINTER(Camera), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_void_p,
+    sig("eo_universe", C.c_int, vp, C.POINTER(CameraT), ip, C.c_int, C.c_int)
+    sig("eo_rgba_from_hsva", None, real, real, real, real, dp)
+    sig("eo_default_camera", C.c_int, C.c_int, dp, C.POINTER(CameraT))
+    sig("eo_scene_camera", C.c_int, vp, C.POINTER(CameraT))
+    sig("eo_render", C.c_int, vp, C.POINTER(CameraT), C.POINTER(Frame), C.c_int, C.c_void_p, C.c_void_p,
         C.POINTER(Stats))
-    sig("eo_trace_path_unknown", C.c_int, vp, dp, dp, C.c_double, dp, dp)
-    sig("eo_camera_update", C.c_int, vp, C.c_int, C.POINTER(Camera), C.POINTER(Input))
+    sig("eo_trace_path_unknown", C.c_int, vp, dp, dp, real, dp, dp)
+    sig("eo_camera_update", C.c_int, vp, C.c_int, C.POINTER(CameraT), C.POINTER(Input))
     sig("eo_test_intersect", C.c_int, vp, C.c_int, dp, dp, C.POINTER(Intersection), C.c_int)
     sig("eo_test_is_point_inside", C.c_int, vp, C.c_int, dp)
-    sig("eo_test_angle_between", C.c_double, C.c_int, dp, dp)
-    sig("eo_test_combine_palette_color", None, dp, dp, C.c_double, dp)
-    sig("eo_test_remainder_f", C.c_double, C.c_double, C.c_double)
+    sig("eo_test_angle_between", real, C.c_int, dp, dp)
+    sig("eo_test_combine_palette_color", None, dp, dp, real, dp)
+    sig("eo_test_remainder_f", real, real, real)
     sig("eo_test_remainder_i", C.c_int64, C.c_int64, C.c_int64)
     sig("eo_test_material_enter", None, vp, C.c_int, dp, C.c_int)
-    sig("eo_test_general_rotation", None, C.c_int, dp, dp, C.c_double, dp)
+    sig("eo_test_general_rotation", None, C.c_int, dp, dp, real, dp)
     sig("eo_test_blend", None, C.c_char_p, dp, dp, dp)
     sig("eo_test_math", None, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
-    sig("eo_test_perlin", C.c_double, C.c_uint32, dp)
+    sig("eo_test_perlin", real, C.c_uint32, dp)
     sig("eo_flops_take", None, C.POINTER(C.c_uint64 * 4))
     sig("eo_build_flags", C.c_int)
-    sig("eo_test_ray", None, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, dp, dp)
+    sig("eo_test_ray", None, C.POINTER(CameraT), C.c_int, C.c_int, C.c_int, C.c_int, dp, dp)
     return L
 
 
@@ -216,6 +232,9 @@ class OracleScene:
     def __init__(self, text, texture_loader=None, random_seed=0, variant=""):
         self.variant = variant
         self.L = lib(variant)
+        self.Camera = Camera32 if variant == "f32" else Camera
+        self.dvec = dvec32 if variant == "f32" else dvec
+        self.real_np = "float32" if variant == "f32" else "float64"
         self.random_seed = random_seed
         self.texture_loader = texture_loader or default_texture_loader([os.getcwd()])
         try:
@@ -304,6 +323,7 @@ class OracleScene:
     # -- registry (scene.rs:620-1408)
     def _build_registry(self):
         L, s, D = self.L, self.s, self.dim
+        dvec, Camera = self.dvec, self.Camera      # the build's F (shadow the module's f64 helpers)
         reg = {}
 
         def add(names, fields, product, fn):
@@ -442,7 +462,7 @@ class OracleScene:
 
     # -- rendering
     def camera(self):
-        c = Camera()
+        c = self.Camera()
         self.L.eo_scene_camera(self.s, C.byref(c))
         return c
 
@@ -475,7 +495,7 @@ class OracleScene:
         r0, r1 = rows if rows else (0, height)
         fr = Frame(width, height, r0, r1, time_ms, 1 if debug_crosshair else 0)
         rgb = np.zeros(((r1 - r0), width, 3), dtype=np.uint8)
-        hit = np.zeros(((r1 - r0), width), dtype=np.float64) if want_hit_t else None
+        hit = np.zeros(((r1 - r0), width), dtype=self.real_np) if want_hit_t else None      # F of the build
         st = Stats()
         threads = threads or default_threads()
         rc = self.L.eo_render(self.s, C.byref(cam), C.byref(fr), threads, rgb.ctypes.data,
