@@ -48,6 +48,9 @@ def parse_args():
                          "sequence driver, images read back to pinned host memory -- the PCIe-inclusive rate")
     ap.add_argument("--slots", type=int, default=2, help="--animate: frames in flight")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
+    ap.add_argument("--low-precision", action="store_true",
+                    help="F = f32: the reference's `low_precision` cargo feature (libeuclider_amd_f32.so against libeo_oracle_f32.so). "
+                         "A separate mode, never the headline: narrower than the reference's default arithmetic")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short runs of BASELINE configs 3, 4 and the 8K frame")
     return ap.parse_args()
 
@@ -87,12 +90,12 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(scene_path, w, h, depth, sample_rows):
+def cpu_baseline(scene_path, w, h, depth, sample_rows, variant=""):
     """The oracle (CPU restatement, kind "port") timed on this host's cores -- a reported baseline.  Also returns the
     oracle's frame (or row band) so that the GPU frame of the timed run can be compared with it."""
     from oracle.scene_loader import load_scene_file
     threads = host_threads()
-    osc = load_scene_file(scene_path)
+    osc = load_scene_file(scene_path, variant=variant)
     runs = 3
     if sample_rows and sample_rows < h:
         r0 = (h - sample_rows) // 2
@@ -243,9 +246,10 @@ def other_configs(torch, dev, stream, Parser):
     """BASELINE.json configs 3 and 4, the extra 4-D scene and the 8K frame on one GPU: a few steps each, so that the driver's
     record carries them too.  Same timing rule as the headline (device-resident, synchronised on both sides)."""
     out = []
-    for scene, W, H, depth, steps in (("3d_hallways.json", 1920, 1080, 12, 5), ("4d_frame.json", 1920, 1080, 8, 5),
-                                      ("4d_cylinders.json", 1920, 1080, 8, 3), ("3d_room.json", 7680, 4320, 8, 2)):
-        env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
+    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 5, False), ("4d_frame.json", 1920, 1080, 8, 5, False),
+                                          ("4d_cylinders.json", 1920, 1080, 8, 3, False), ("3d_room.json", 7680, 4320, 8, 2, False),
+                                          ("3d_room.json", 1920, 1080, 8, 5, True)):
+        env = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
         env.camera.max_depth = depth
         frame = env.frame(W, H, time=0.0, rows=(0, H))
         rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -266,7 +270,8 @@ def other_configs(torch, dev, stream, Parser):
         kernel_ms = sum(kms) / max(1, len(kms))
         alg = 4.0 * W * H + 16.0 * st["bg_samples"] + env.info.flat_bytes
         ach = alg / (kernel_ms * 1e-3) / 1e9
-        out.append({"workload": "%s %dx%d depth %d" % (scene, W, H, depth), "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
+        out.append({"workload": "%s %dx%d depth %d%s" % (scene, W, H, depth, ", low_precision (F = f32, its own rays and pixels)" if lp else ""),
+                    "dtype": "f32" if lp else "f64", "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
                     "ms_per_step": dt * 1e3, "steps": steps, "rays_per_frame": int(st["rays"]),
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -308,7 +313,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
-    env = Parser().parse_file(scene_path)
+    env = Parser(low_precision=args.low_precision).parse_file(scene_path)
     env.camera.max_depth = args.max_depth
     if args.animate:
         if world != 1:
@@ -414,8 +419,8 @@ def main():
             "metric": "Mray/s (primary+secondary) at 1920\u00d71080 depth-8; frac of HBM roofline",     # BASELINE.json's metric, verbatim
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.fixed_frame else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
+            "vs_baseline": None, "dtype": "f32" if args.low_precision else "f64", "data": "synthetic",
+            "config": {"workload": workload + (" low_precision (F = f32: a separate mode, not the headline)" if args.low_precision else ""), "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
@@ -429,7 +434,7 @@ def main():
             out["config5"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
-            cb, orgb, rows, ost = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows)
+            cb, orgb, rows, ost = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows, "f32" if args.low_precision else "")
             out["cpu_baseline"] = cb
             out["config"]["gpu_over_cpu"] = value / cb["value"]
             # the frame the timed run left in HBM against the oracle's frame of the same inputs (whole frame unless --cpu-sample-rows)
@@ -439,7 +444,7 @@ def main():
             out["parity"] = {"bytes_compared": int(orgb.size), "mismatch": int((gpu_rgb != orgb).sum()),
                              "rays_equal": (rows is None and int(st["rays"]) == int(ost["rays"])) if rows is None else None,
                              "checked_against": "oracle/ (CPU restatement), same scene, camera, frame"}
-        if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json":
+        if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json" and not args.low_precision:
             del rgb_out
             out["other_configs"] = other_configs(torch, dev, stream, Parser)
         print(json.dumps(out), flush=True)

@@ -475,7 +475,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     if (r->prepare_only) return EU_OK;      /* buffers, streams and events exist now: nothing is allocated while the frame is in flight */
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     if (r->dbg_hs_cap) hs_cap = r->dbg_hs_cap;      /* diagnostics only */
-    const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * 12;     /* the intersect kernel reads the scene through scalar loads */
+    const size_t isect_lds = (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * (sizeof(double) + 4);     /* (t, code) per entry; the intersect kernel reads the scene through scalar loads */
     unsigned g_isect, g_res;
     const bool hs_lds = r->hit_cap <= 32 && !r->dbg_hs_private;      /* else: private (scratch) hit stack */
     const bool hs_small = !hs_lds && r->hit_cap <= 16;

@@ -40,6 +40,9 @@
 #define EU_WF_WIN 1024        /* rays sorted together in the shade kernel */
 #endif
 #define EU_WF_KEYS 32
+#ifndef EU_ISECT_WAVES
+#define EU_ISECT_WAVES 3     /* waves per SIMD the intersect kernel is compiled for */
+#endif
 #ifndef EU_SHADE_WAVES
 #define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
 #endif
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *
 
 /* ------------------------------------------------------------------ trace_closest */
 template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
-__global__ __launch_bounds__(EU_WF_BLOCK, 3) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
                                                                       EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {
     extern __shared__ uint64_t lds_dyn[];
     EuScene S;
