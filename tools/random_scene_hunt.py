@@ -8,14 +8,15 @@ from oracle.scene_loader import OracleScene, default_texture_loader
 ROOT = os.getcwd()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 W, H, DEPTH = int(os.environ.get("HUNT_W", 40)), int(os.environ.get("HUNT_H", 30)), int(os.environ.get("HUNT_DEPTH", 5))
+F32 = os.environ.get("HUNT_F32") == "1"      # the low_precision pair: libeuclider_amd_f32.so against libeo_oracle_f32.so
 bad = []; undefined = 0; skipped = 0
 for seed in range(lo, hi):
     if seed % 200 == 0: print("at seed", seed, "bad so far", len(bad), flush=True)
     text, dim = random_scene(seed)
     try:
-        osc = OracleScene(text, default_texture_loader([ROOT]))
+        osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if F32 else "")
         orgb, ohit, ost = osc.render(W, H, max_depth=DEPTH, time_ms=100 * (seed % 7), want_hit_t=True, threads=8)
-        env = Parser(texture_dirs=[ROOT]).parse(text)
+        env = Parser(texture_dirs=[ROOT], low_precision=F32).parse(text)
     except Exception as e:
         skipped += 1; continue
     env.camera.max_depth = DEPTH
@@ -30,7 +31,8 @@ for seed in range(lo, hi):
     if not np.array_equal(img.data, orgb) or img.stats != ost:
         bad.append((seed, int((img.data != orgb).sum()), img.stats, ost))
         continue
-    nn = ~(np.isnan(img.hit_t) & np.isnan(ohit))
-    if not np.array_equal(img.hit_t[nn], ohit[nn]): bad.append((seed, "hit_t"))
-print("seeds", lo, hi, "bad", len(bad), "undefined", undefined, "skipped", skipped)
+    gh = img.hit_t.astype(ohit.dtype)
+    nn = ~(np.isnan(gh) & np.isnan(ohit))
+    if not np.array_equal(gh[nn], ohit[nn]): bad.append((seed, "hit_t"))
+print("kernel", os.environ.get("EU_KERNEL", "wavefront"), "f32" if F32 else "f64", "%dx%d depth %d" % (W, H, DEPTH), "seeds", lo, hi, "bad", len(bad), "undefined", undefined, "skipped", skipped)
 for b in bad[:20]: print(b)
