@@ -85,6 +85,7 @@ SYMBOLS = {
     "eu_renderer_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "eu_renderer_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "eu_renderer_kernel_ms_history": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "eu_renderer_retraces": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "eu_renderer_debug_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "eu_renderer_debug_generations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "eu_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,

@@ -107,6 +107,7 @@ struct eu_renderer {
     size_t ts_node_chunks = 0;
     unsigned ts_grid_last = 0;               /* grid of the most recent launch: that many counter rows are valid */
     bool ts_last = false;                    /* the most recent frame went through the stream kernel */
+    uint64_t retraces = 0;                   /* frames eu_render traced a second time (queue / node-pool overflow): eu_renderer_retraces */
     double ts_node_factor = R(6.0);             /* node slots per pixel (EU_TS_NODE_FACTOR); eu_render doubles it after an overflow */
     unsigned ts_grid_limit = 0;              /* EU_TS_GRID: fewer workgroups than the chip holds (diagnostics) */
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
@@ -782,6 +783,12 @@ extern "C" int eu_renderer_kernel_ms(eu_renderer *r, float *ms) {
     return eu_renderer_kernel_ms_history(r, ms, 1) == 1 ? EU_OK : EU_ERR_INVALID_ARGUMENT;
 }
 
+extern "C" int eu_renderer_retraces(eu_renderer *r, uint64_t *count) {
+    if (!r || !count) return EU_ERR_INVALID_ARGUMENT;
+    *count = r->retraces;
+    return EU_OK;
+}
+
 extern "C" int eu_renderer_kernel_ms_history(eu_renderer *r, float *ms, int max_n) {
     if (!r || !ms || max_n < 1) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
@@ -827,6 +834,7 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
             const int src = eu_renderer_stats(r, &tmp);
             if (src != EU_ERR_CAPACITY) break;
             r->ts_node_factor = r->ts_node_factor * R(2.0) > R(2.0) ? r->ts_node_factor * R(2.0) : R(2.0);
+            r->retraces++;
             rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
             if (rc != EU_OK) return rc;
         }
@@ -838,6 +846,7 @@ extern "C" int eu_render(eu_renderer *r, const eu_camera *cam, const eu_frame *f
         HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
         if (c.overflow) {
             r->use_wavefront = false;
+            r->retraces++;
             rc = render_device_impl(r, cam, f, nullptr, r->d_rgba, hit_t_host ? r->d_hit : nullptr, nullptr);
             r->use_wavefront = true;
             if (rc != EU_OK) return rc;

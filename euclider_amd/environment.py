@@ -220,6 +220,13 @@ class Environment:
             raise EuError(rc)
         return ms.value
 
+    def retraces(self, device=0):
+        """Frames `render` had to trace a second time (queue / node-pool overflow): the slow path, see eu_renderer_retraces."""
+        n = C.c_uint64()
+        rc = self._L.eu_renderer_retraces(self.renderer(device), C.byref(n))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return n.value
 
     def kernel_ms_history(self, n, device=0):
         buf = (C.c_float * max(1, n))()

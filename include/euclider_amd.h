@@ -128,6 +128,12 @@ int eu_renderer_stats(eu_renderer *, eu_stats *);
 int eu_renderer_kernel_ms(eu_renderer *, float *ms);
 /* The same for the most recent min(max_n, 64) launches, oldest first; returns how many were written. */
 int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
+/* Number of frames eu_render had to trace a second time since the renderer was created: a frame whose recursion fans out
+ * beyond the ray queues (more than EU_WF_RAY_FACTOR rays per pixel in one generation) is traced again by the stack-based
+ * kernel, several times slower; a frame that exhausts the stream kernel's tree-node pool is traced again with a larger pool.
+ * The result is the same either way; this counter is how a caller notices the slow path (the asynchronous sequence does not
+ * retry, it reports EU_ERR_CAPACITY). */
+int eu_renderer_retraces(eu_renderer *, uint64_t *count);
 
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
  * (refill, intersect, shade, return); all zero in the shipped build. */

@@ -316,6 +316,7 @@ def test_node_pool_overflow_is_reported_and_retried(monkeypatch):
         assert ei.value.code == _capi.EU_ERR_CAPACITY
     retried = b.render((1920, 1080))
     assert np.array_equal(retried.data, good.data) and retried.stats == good.stats
+    assert b.retraces() >= 1          # the slow path is visible to the caller
     b.close()
 
 
@@ -327,14 +328,17 @@ def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
     a = Parser().parse_file(path)
     a.camera.max_depth = 4
     good = a.render((1920, 1080))
+    assert a.retraces() == 0
     a.close()
     monkeypatch.setenv("EU_KERNEL", "wavefront")
     monkeypatch.setenv("EU_WF_RAY_FACTOR", "0.05")
     monkeypatch.setenv("EU_WF_STREAMS", "1")
     b = Parser().parse_file(path)
     b.camera.max_depth = 4
+    assert b.retraces() == 0
     fell_back = b.render((1920, 1080))
     assert np.array_equal(fell_back.data, good.data) and fell_back.stats == good.stats
+    assert b.retraces() == 1          # the slow path is visible to the caller
     from euclider_amd import FrameSequence
     from euclider_amd.environment import EuError
     with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
