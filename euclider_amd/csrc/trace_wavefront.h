@@ -43,6 +43,9 @@
 #ifndef EU_ISECT_WAVES
 #define EU_ISECT_WAVES 3     /* waves per SIMD the intersect kernel is compiled for */
 #endif
+#ifndef EU_ISECT_PREFETCH
+#define EU_ISECT_PREFETCH 1  /* the next ray's loads are issued before the current ray is intersected */
+#endif
 #ifndef EU_SHADE_WAVES
 #define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
 #endif
@@ -116,7 +119,9 @@ EU_DEV uint32_t wf_append_local(uint32_t *lds_counter, uint32_t n /* 0..2 slots 
 /* Balanced consumption of a segmented queue: every workgroup scans the (<= 1024) segment lengths of
  * the generation into LDS; the rays then form one virtual index space that is dealt out grid-stride,
  * and a lane maps its virtual index back to (segment, offset) with a binary search in LDS. */
+#ifndef EU_WF_MAX_SEG
 #define EU_WF_MAX_SEG 1024
+#endif
 EU_DEV uint32_t wf_build_prefix(const uint32_t *seg_count, uint32_t n_seg, uint32_t *pref /* LDS, n_seg + 1 words */, uint32_t *wave_tot /* LDS, 4 words */) {
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t v[4], s = 0;
@@ -301,11 +306,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
             double o[D], d[D];
 #pragma unroll
             for (int k = 0; k < D; k++) { o[k] = o_next[k]; d[k] = d_next[k]; }
+#if EU_ISECT_PREFETCH
             if (v + v_step < total) {
                 i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
 #pragma unroll
                 for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
             }
+#endif
             cnt.rays++;
             IS_STAMP(14);
             /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  A wave whose rays are
@@ -347,6 +354,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
             if (__ballot(fail) == 0ull) { cnt = c1; break; }
             use_box = false;
             }
+#if !EU_ISECT_PREFETCH      /* (123 instead of 137 VGPRs; measured equal) */
+            if (v + v_step < total) {
+                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+#pragma unroll
+                for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+            }
+#endif
             B.hit_t[i] = best_t;
             B.hit_code[i] = best_code;
             B.hit_ent[i] = best_ent;
