@@ -1866,6 +1866,27 @@ void eo_test_material_enter(const eo_scene *s, int material, double *direction, 
     free(t.arena);
 }
 void eo_test_general_rotation(int dim, const double *self, const double *other, double angle, double *vec) { general_rotation(dim, self, other, angle, vec); }
+/* Fresnel ratio / Snell direction for one hit: `direction` is the ray's direction at the hit, `normal_closer` the surface normal on the
+ * side the ray comes from (TracingContext::normal_closer, shape.rs:111-125) */
+double eo_test_fresnel(int dim, double index_inside, double index_outside, const double *direction, const double *normal_closer, int exiting) {
+    tctx t; memset(&t, 0, sizeof t); t.D = dim;
+    obj p; memset(&p, 0, sizeof p); p.sub = RATIO_FRESNEL; p.p0 = index_inside; p.p1 = index_outside;
+    trace_ctx c; memset(&c, 0, sizeof c);
+    for (int i = 0; i < dim; i++) { c.intersection.direction[i] = direction[i]; c.normal_closer[i] = normal_closer[i]; }
+    c.exiting = exiting;
+    return reflection_ratio(&t, &p, &c);
+}
+void eo_test_snell(int dim, double index, const double *direction, const double *normal_closer, int exiting, double *out) {
+    tctx t; memset(&t, 0, sizeof t); t.D = dim;
+    obj p; memset(&p, 0, sizeof p); p.sub = THR_SNELL; p.p0 = index;
+    trace_ctx c; memset(&c, 0, sizeof c);
+    for (int i = 0; i < dim; i++) { c.intersection.direction[i] = direction[i]; c.normal_closer[i] = normal_closer[i]; }
+    c.exiting = exiting;
+    double o[MAXD];
+    threshold_direction(&t, &p, &c, o);
+    for (int i = 0; i < dim; i++) out[i] = o[i];
+}
+void eo_test_to_pixel(const double *rgba, uint8_t *px) { rgba_t c = rgba_of(rgba); to_pixel4(NULL, c, px); }
 void eo_test_blend(const char *name, const double *src, const double *dst, double *out) {
     int fn = -1;
     for (int i = 0; i < BL_COUNT; i++) if (!strcmp(name, BLEND_NAMES[i])) fn = i;

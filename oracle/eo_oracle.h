@@ -147,6 +147,9 @@ double eo_test_remainder_f(double a, double b);
 int64_t eo_test_remainder_i(int64_t a, int64_t b);
 void eo_test_material_enter(const eo_scene *, int material, double *direction, int exit);
 void eo_test_general_rotation(int dim, const double *self, const double *other, double angle, double *vec);
+double eo_test_fresnel(int dim, double index_inside, double index_outside, const double *direction, const double *normal_closer, int exiting);
+void eo_test_snell(int dim, double index, const double *direction, const double *normal_closer, int exiting, double *out);
+void eo_test_to_pixel(const double *rgba, uint8_t *px);
 void eo_test_blend(const char *name, const double *src, const double *dst, double *out);
 void eo_test_math(int fn, const double *x, const double *y, double *out, int n);
 double eo_test_perlin(uint32_t seed, const double *xyzw);

@@ -145,6 +145,9 @@ def lib(variant=""):
     sig("eo_test_material_enter", None, vp, C.c_int, dp, C.c_int)
     sig("eo_test_general_rotation", None, C.c_int, dp, dp, real, dp)
     sig("eo_test_blend", None, C.c_char_p, dp, dp, dp)
+    sig("eo_test_fresnel", real, C.c_int, real, real, dp, dp, C.c_int)
+    sig("eo_test_snell", None, C.c_int, real, dp, dp, C.c_int, dp)
+    sig("eo_test_to_pixel", None, dp, C.POINTER(C.c_uint8))
     sig("eo_test_math", None, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
     sig("eo_test_perlin", real, C.c_uint32, dp)
     sig("eo_flops_take", None, C.POINTER(C.c_uint64 * 4))

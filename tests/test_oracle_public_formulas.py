@@ -144,6 +144,11 @@ def dot(a, b): return sum(x * y for x, y in zip(a, b))
 def norm(a): return math.sqrt(dot(a, a))
 
 
+def unit(v):
+    n = norm(v)
+    return [x / n for x in v]
+
+
 @pytest.mark.parametrize("dim", [3, 4])
 def test_general_rotation_is_a_plane_rotation(oracle_lib, dim):
     r = random.Random(dim)
@@ -190,3 +195,98 @@ def test_general_rotation_singular_plane_is_nan(oracle_lib):
     assert all(math.isnan(x) for x in w)
     w4 = rotate(oracle_lib, 4, [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0], 0.25, [0.0, 0.0, 1.0, 0.0])
     assert all(math.isnan(x) for x in w4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fresnel / Snell (surface.rs:213-244, 268-288) against the textbook laws, to_pixel (palette RgbPixel for [u8; 4]) against
+# the scene files' own colour constants.
+
+N_AXIS = {3: unit([0.3, -0.5, 0.8]), 4: unit([0.3, -0.5, 0.8, 0.2])}      # (a normal along z would hit general_rotation's singular plane)
+U_AXIS = {}
+for _dim, _n in N_AXIS.items():
+    _u = [1.0, 0.4, 0.1, -0.3][:_dim]
+    _k = dot(_u, _n)
+    U_AXIS[_dim] = unit([a - _k * b for a, b in zip(_u, _n)])
+
+
+def incident(theta, dim=3):
+    """A ray arriving at a surface with normal_closer = n at angle `theta` from the normal, in the plane spanned by (n, u)."""
+    n, u = N_AXIS[dim], U_AXIS[dim]
+    return [math.sin(theta) * a - math.cos(theta) * b for a, b in zip(u, n)], n
+
+
+def fresnel_textbook(n1, n2, ti):
+    st = n1 / n2 * math.sin(ti)
+    if st > 1.0:
+        return 1.0
+    tt = math.asin(st)
+    rs = ((n1 * math.cos(ti) - n2 * math.cos(tt)) / (n1 * math.cos(ti) + n2 * math.cos(tt))) ** 2
+    rp = ((n1 * math.cos(tt) - n2 * math.cos(ti)) / (n1 * math.cos(tt) + n2 * math.cos(ti))) ** 2
+    return (rs + rp) / 2
+
+
+@pytest.mark.parametrize("dim", [3, 4])
+def test_fresnel_matches_the_textbook(oracle_lib, dim):
+    n_in, n_out = 1.458, 1.0                               # fused silica in vacuum (scenes/3d_fresnel.json)
+    # normal incidence: ((n1 - n2) / (n1 + n2))^2 = 0.034719... from either side
+    d, n = incident(0.0, dim)
+    r0 = ((n_in - n_out) / (n_in + n_out)) ** 2
+    assert abs(oracle_lib.eo_test_fresnel(dim, n_in, n_out, dvec(d), dvec(n), 0) - r0) <= 1e-12
+    assert abs(oracle_lib.eo_test_fresnel(dim, n_in, n_out, dvec(d), dvec(n), 1) - r0) <= 1e-12
+    # entering, over the whole range of angles
+    for k in range(1, 90):
+        ti = math.radians(k)
+        d, n = incident(ti, dim)
+        got = oracle_lib.eo_test_fresnel(dim, n_in, n_out, dvec(d), dvec(n), 0)
+        assert abs(got - fresnel_textbook(n_out, n_in, ti)) <= 1e-9, k
+    # Brewster's angle: the p component vanishes, R = Rs / 2
+    tb = math.atan(n_in / n_out)
+    d, n = incident(tb, dim)
+    tt = math.asin(n_out / n_in * math.sin(tb))
+    rs = ((n_out * math.cos(tb) - n_in * math.cos(tt)) / (n_out * math.cos(tb) + n_in * math.cos(tt))) ** 2
+    assert abs(oracle_lib.eo_test_fresnel(dim, n_in, n_out, dvec(d), dvec(n), 0) - rs / 2) <= 1e-12
+    # leaving the glass: total internal reflection beyond asin(1 / 1.458) = 43.3 degrees
+    crit = math.degrees(math.asin(n_out / n_in))
+    for k in range(1, 90):
+        ti = math.radians(k)
+        d, n = incident(ti, dim)
+        got = oracle_lib.eo_test_fresnel(dim, n_in, n_out, dvec(d), dvec(n), 1)
+        if k > crit + 0.5:
+            assert got == 1.0, k
+        elif k < crit - 0.5:
+            assert abs(got - fresnel_textbook(n_in, n_out, ti)) <= 1e-9, k
+
+
+@pytest.mark.parametrize("dim", [3, 4])
+def test_snell_direction_obeys_snells_law(oracle_lib, dim):
+    n_glass = 1.458
+    for exiting, n1, n2 in ((0, 1.0, n_glass), (1, n_glass, 1.0)):
+        for k in range(1, 89):
+            ti = math.radians(k)
+            if n1 / n2 * math.sin(ti) >= 1.0:
+                continue                                   # (total internal reflection: the ratio provider returned 1, no transmission)
+            d, n = incident(ti, dim)
+            out = dvec([0.0] * 4)
+            oracle_lib.eo_test_snell(dim, n_glass, dvec(d), dvec(n), exiting, out)
+            o = list(out)[:dim]
+            assert abs(norm(o) - 1.0) <= 1e-12              # a rotation of a unit vector
+            along_u, along_n = dot(o, U_AXIS[dim]), dot(o, n)
+            rest = [x - along_u * a - along_n * b for x, a, b in zip(o, U_AXIS[dim], n)]
+            assert all(abs(x) <= 1e-12 for x in rest)       # stays in the plane of incidence
+            assert along_n < 0.0 and along_u > 0.0          # goes on through the surface, same side of the normal
+            tt = math.atan2(along_u, -along_n)
+            assert abs(n1 * math.sin(ti) - n2 * math.sin(tt)) <= 1e-9, (exiting, k)
+
+
+def test_to_pixel_truncates_and_clamps(oracle_lib):
+    """u8 = trunc(clamp(c, 0, 1) * 255): the inverse of Rgba::new_u8 (c = u8 / 255) on every byte value, no rounding up, no
+    gamma.  (255 * (k / 255) is k or k - 1ulp-ish in floating point: k / 255 * 255 must not fall below k for the scenes' own
+    constants to survive a round trip -- it does not, for any k.)"""
+    import ctypes as C
+    px = (C.c_uint8 * 4)()
+    for k in range(256):
+        oracle_lib.eo_test_to_pixel(dvec([k / 255.0, (k + 0.999) / 255.0 if k < 255 else 1.0, -0.5, 7.0]), px)
+        assert (px[0], px[2], px[3]) == (k, 0, 255)
+        assert px[1] == k                                   # truncation: 0.999 of a step short of k + 1 is still k
+    oracle_lib.eo_test_to_pixel(dvec([0.5, 0.25, 0.999, 1.0]), px)
+    assert list(px) == [127, 63, 254, 255]                  # 127.5 -> 127 (a rounding to_pixel would give 128)
