@@ -696,6 +696,9 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if (emit) {
                 if (o0 + no >= CAP) { if (!(i == root && no > 0)) cnt.errors++; break; }   /* capacity (the loader's bound is na + nb) */
                 hs.set(o0 + no, t, c); no++;
+                /* trace_closest asks an entity's stream for element 0 only (universe/mod.rs:114) and the reference's iterators are
+                 * lazy: what the root's merge would produce after its first element is never computed there */
+                if (i == root) break;
             }
             if (end) break;
         }
