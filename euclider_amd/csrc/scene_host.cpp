@@ -753,6 +753,7 @@ struct Flattener {
                 else if (!(l.a[i] == R(0.0))) return false;
             }
             if (!std::isfinite(l.r) || l.r == R(0.0)) return false;
+            if (!(l.signum == R(1.0) || l.signum == -R(1.0))) return false;      /* (the device compares sign bits, chain_matrices_box) */
         }
         return true;
     }

@@ -321,7 +321,13 @@ template <int D> struct FrameStack {
     double data[EU_MAX_DEPTH][2 * D];
 };
 
+#ifdef EU_PROFILE_SHAPE      /* diagnostic build: s_memtime shares of eval_shape's parts -> EuDevCounters::phase[] (tools/shape_profile.py) */
+struct LaneCounters { uint32_t rays, bg, nan_px, errors; unsigned long long ph[8], last; };
+#define SHP(c, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (c).ph[(k)] += now_ - (c).last; (c).last = now_; } while (0)
+#else
 struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
+#define SHP(c, k) do { } while (0)
+#endif
 
 struct Rgba { double r, g, b, a; };
 
@@ -359,7 +365,7 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
 #pragma unroll
     for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
-        if (i < n) {
+        if (i < n && ((pres >> i) & 1u)) {      /* a leaf without a hit (t < 0) never enters a list: its row is never read (chain_merge) */
             double loc[D];
 #pragma unroll
             for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * tk[i];
@@ -415,7 +421,7 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) { in_k[k] = 0; lt_k[k] = 0; }
 #pragma unroll
     for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
-        if (i < n) {
+        if (i < n && ((pres >> i) & 1u)) {      /* (rows of leaves without a hit are never read) */
             double loc[D];
 #pragma unroll
             for (int m = 0; m < D; m++) { loc[m] = o[m] + d[m] * tk[i]; ok = ok && __builtin_isfinite(loc[m]); }
@@ -424,7 +430,9 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
                 if (j < n && j != i) {
                     const double *Pj = P + j * EU_HS_STRIDE(D);
                     const double r = Pj[j / 2] * loc[j / 2] + Pj[D];
-                    if (Pj[D + 1] == rust_signum(r)) in_k[j] |= 1u << i;
+                    /* signum_j == rust_signum(r) (shape.rs:874-880): signum_j is +-1 (the loader only calls such chains boxes) and r is
+                     * finite when loc is (else the result is discarded), so the two are equal exactly when their sign bits are */
+                    if (((eu_hi(Pj[D + 1]) ^ eu_hi(r)) >> 31) == 0u) in_k[j] |= 1u << i;
                     if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
                 }
             }
@@ -436,6 +444,18 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
 
 template <int D>
 EU_DEV uint32_t chain_merge(bool is_union, uint32_t n, uint32_t pres, const uint32_t (&in_k)[EU_CHAIN_MAX], const uint32_t (&lt_k)[EU_CHAIN_MAX], uint32_t &list_out) {
+    {   /* A hit reaches the end of the cascade only if every level lets it through: at its own level k it is the B element and
+         * must pass inside_of_A (Intersection: all earlier leaves contain it, Union: none does); at every later level j it is an A
+         * element and is emitted only if leaf j contains it (Intersection) / does not (Union); an element that fails is never
+         * emitted later (it is skipped or it ends the stream).  So the final list only holds hits that pass the test of EVERY other
+         * leaf; if no present hit does, the stream is empty whatever the order of the merges. */
+        uint32_t acc = is_union ? 0u : 0xffffffffu;
+#pragma unroll
+        for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
+            if (j < n) { if (is_union) acc |= in_k[j] & ~(1u << j); else acc &= in_k[j] | (1u << j); }
+        }
+        if (((is_union ? ~acc : acc) & pres & ((1u << n) - 1u)) == 0u) { list_out = 0; return 0; }
+    }
     uint32_t list = 0, len = (pres & 1u);
 #pragma unroll
     for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) {
@@ -472,12 +492,19 @@ EU_DEV uint32_t chain_merge(bool is_union, uint32_t n, uint32_t pres, const uint
  * then meaningless) and the caller traces the wave's rays again with use_box = false, where a box is an ordinary Intersection chain. */
 template <int D>
 EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const double *P, const double *o, const double *d,
-                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out, bool use_box, bool &fail) {
+                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out, bool use_box, bool &fail, LaneCounters *prof = nullptr) {
     uint32_t pres = 0, in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];
     if (use_box && kind == EU_SH_CHAIN_BOX) {      /* wave-uniform */
         if (!chain_matrices_box<D>(P, o, d, tk, pres, in_k, lt_k)) fail = true;
     } else chain_matrices<D>(n, P, o, d, tk, pres, in_k, lt_k);
-    return chain_merge<D>(kind == EU_SH_CHAIN_UNION, n, pres, in_k, lt_k, list_out);
+#ifdef EU_PROFILE_SHAPE
+    if (prof) { __builtin_amdgcn_wave_barrier(); SHP(*prof, 1); }
+#endif
+    const uint32_t len = chain_merge<D>(kind == EU_SH_CHAIN_UNION, n, pres, in_k, lt_k, list_out);
+#ifdef EU_PROFILE_SHAPE
+    if (prof) { __builtin_amdgcn_wave_barrier(); SHP(*prof, 2); }
+#endif
+    return len;
 }
 
 /* First element of a Union chain's stream without building the streams (trace_closest only looks at element 0,
@@ -605,9 +632,17 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
+            SHP(cnt, 6);
             if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
-            else if (!(Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)))
+            else if (!(Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d))) {
+                SHP(cnt, 0);
+#ifdef EU_PROFILE_SHAPE
+                n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail, &cnt);
+#else
                 n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
+#endif
+            }
+            SHP(cnt, 0);
             if (n) {
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
@@ -619,9 +654,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             sp += n;
             lens = (lens << 8) | (uint64_t)n;
             unk <<= 1;
+            SHP(cnt, 3);
             continue;
         }
         if (kind < EU_SH_UNION) {
+            SHP(cnt, 6);
             const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
             int n = lh.n;
             if (sp + 2 > CAP) { cnt.errors++; n = 0; }
@@ -630,8 +667,10 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             sp += (uint32_t)n;
             lens = (lens << 8) | (uint64_t)n;
             unk <<= 1;
+            SHP(cnt, 4);
             continue;
         }
+        SHP(cnt, 6);
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
         uint32_t kb, fb, pb, cb_;
         S.op(i - 1, kb, fb, pb, cb_);
@@ -703,6 +742,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
             if (end) break;
         }
         for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
+        SHP(cnt, 5);
         sp = a0 + no;
         lens = (lens << 8) | (uint64_t)(no | (out_rep ? 0x80u : 0u));
         unk = (unk << 1) | (out_unk ? 1u : 0u);

@@ -93,6 +93,9 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
         if (v3) atomicAdd(&wg_cnt[3], v3);
     }
     __syncthreads();
+#ifdef EU_PROFILE_SHAPE
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) if (cnt.ph[q]) atomicAdd(&counters->phase[q], cnt.ph[q]);
+#endif
     if (threadIdx.x == 0) {
         if (wg_cnt[0]) atomicAdd(&counters->rays, wg_cnt[0]);
         if (wg_cnt[1]) atomicAdd(&counters->bg_samples, wg_cnt[1]);
@@ -274,6 +277,10 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
         HS.cap = hs_cap;
     }
     LaneCounters cnt = {0, 0, 0, 0};
+#ifdef EU_PROFILE_SHAPE
+    for (int q = 0; q < 8; q++) cnt.ph[q] = 0;
+    cnt.last = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef EU_PROFILE_ISECT       /* diagnostic build: cycles per entity slot (phase[e], e < 14), ray load (14), result store (15) */
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
 #define IS_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last_; last_ = now_; } while (0)

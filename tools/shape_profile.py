@@ -1,0 +1,25 @@
+"""Diagnostic: where eval_shape spends a wave's time (needs a -DEU_PROFILE_SHAPE build, e.g. EU_LIB_PATH=variants/shape_prof.so).
+Usage: python tools/shape_profile.py [scene] [depth] [w] [h]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from euclider_amd import Parser, _capi  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "4d_frame.json"
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+h = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
+env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
+env.camera.max_depth = depth
+img = env.render((w, h))
+ph = (C.c_uint64 * 16)()
+_capi.lib().eu_renderer_debug_phases(env.renderer(0), ph)
+tot = float(sum(ph[:8])) or 1.0
+print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"])
+names = ["chain: bound test, set-up", "chain: matrices (t_k, IN, LT)", "chain: merge cascade", "chain: push to the hit stack", "leaf ops",
+         "composite merges (incl. inside tests)", "outside eval_shape's ops (ray load, entity loop, result)", "-"]
+for i in range(7):
+    print("  %-58s %6.2f%%" % (names[i], 100.0 * ph[i] / tot))
