@@ -593,28 +593,37 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
                            HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c, bool use_box, bool &fail) {
     if (first == root) {   /* a bare leaf or chain: no list machinery */
         uint32_t kind, f, param, count;
+        SHP(cnt, 6);
         S.op(root, kind, f, param, count);
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list;
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
-            if (Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)) return 0u;
+            if (Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)) { SHP(cnt, 0); return 0u; }
+            SHP(cnt, 0);
             if (kind == EU_SH_CHAIN_UNION) {
                 double tf = R(0.0); uint32_t idx = 0;
                 const int q = union_chain_first<D>(count, Pc, o, d, tf, idx);
+                SHP(cnt, 7);
                 if (q == 0) return 0u;
                 if (q > 0) { first_t = tf; first_c = root | (idx << 16); return 1u; }
             }
+#ifdef EU_PROFILE_SHAPE
+            const uint32_t n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail, &cnt);
+#else
             const uint32_t n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
+#endif
             if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
 #pragma unroll
                 for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
                 first_t = hs.gt(list & 15u); first_c = root | ((list & 15u) << 16);
             }
+            SHP(cnt, 3);
             return n;
         }
         const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
         if (lh.n) { first_t = lh.t0; first_c = root; }
+        SHP(cnt, 4);
         return (uint32_t)lh.n;
     }
     const uint32_t CAP = hs.cap;

@@ -20,6 +20,6 @@ _capi.lib().eu_renderer_debug_phases(env.renderer(0), ph)
 tot = float(sum(ph[:8])) or 1.0
 print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"])
 names = ["chain: bound test, set-up", "chain: matrices (t_k, IN, LT)", "chain: merge cascade", "chain: push to the hit stack", "leaf ops",
-         "composite merges (incl. inside tests)", "outside eval_shape's ops (ray load, entity loop, result)", "-"]
-for i in range(7):
-    print("  %-58s %6.2f%%" % (names[i], 100.0 * ph[i] / tot))
+         "composite merges (incl. inside tests)", "outside eval_shape's ops (ray load, entity loop, entity bound test, result)", "top-level Union chain: first element directly"]
+for i in range(8):
+    print("  %-78s %6.2f%%" % (names[i], 100.0 * ph[i] / tot))
