@@ -321,6 +321,25 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
             }
 #endif
             cnt.rays++;
+#ifdef EU_EXP_DUMMY_VALU      /* experiment ("what an instruction costs"): EU_EXP_DUMMY_VALU extra f64 VALU instructions per ray batch, 4 independent chains */
+            {
+                double a0 = o[0], a1 = o[1], a2 = d[0], a3 = d[1];
+#pragma unroll
+                for (int q = 0; q < EU_EXP_DUMMY_VALU / 4; q++) {
+                    asm volatile("v_add_f64 %0, %0, %0" : "+v"(a0)); asm volatile("v_add_f64 %0, %0, %0" : "+v"(a1));
+                    asm volatile("v_add_f64 %0, %0, %0" : "+v"(a2)); asm volatile("v_add_f64 %0, %0, %0" : "+v"(a3));
+                }
+                if (a0 + a1 + a2 + a3 == R(12345.678)) cnt.errors++;
+            }
+#endif
+#ifdef EU_EXP_DUMMY_SALU      /* experiment: EU_EXP_DUMMY_SALU extra SALU instructions per ray batch */
+            {
+                uint32_t s0 = gen;
+#pragma unroll
+                for (int q = 0; q < EU_EXP_DUMMY_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
+                if (s0 == 0x12345678u) cnt.errors++;
+            }
+#endif
             IS_STAMP(14);
             /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  A wave whose rays are
              * all regular (finite, no zero direction component) evaluates box chains with one product per dot product
