@@ -339,13 +339,10 @@ static int wf_ensure(eu_renderer *r, size_t pixels, uint32_t max_depth, int n_se
     };
     int rc;
     for (int k = 0; k < 2; k++) {
-        if ((rc = alloc((void **)&B.ray_od[k], ray_cap * 2 * D * sizeof(double)))) return rc;
-        if ((rc = alloc((void **)&B.ray_parent[k], ray_cap * 4))) return rc;
-        if ((rc = alloc((void **)&B.ray_aux[k], ray_cap * 4))) return rc;
+        if ((rc = alloc((void **)&B.ray[k], ray_cap * 2 * D * sizeof(double)))) return rc;
+        if ((rc = alloc((void **)&B.ray_pa[k], ray_cap * sizeof(uint2)))) return rc;
     }
-    if ((rc = alloc((void **)&B.hit_t, ray_cap * 8))) return rc;
-    if ((rc = alloc((void **)&B.hit_code, ray_cap * 4))) return rc;
-    if ((rc = alloc((void **)&B.hit_ent, ray_cap * 4))) return rc;
+    if ((rc = alloc((void **)&B.hit, ray_cap * sizeof(EuWfHit)))) return rc;
     /* node ids are static: pixel roots, then generation g's queue slot q at pixels + g*ray_cap + q
      * (only the slots that hold rays are ever touched) */
     /* the finish step's pool: its node chunks lie behind the pipeline's slots in the same array (one id space for deliveries) */
@@ -441,7 +438,7 @@ static int wf_launch_finish(eu_renderer *r, hipStream_t stream, int set, uint32_
     prm.cam = dc; prm.fr = df; prm.P = r->wf_fin[set];
     prm.counters = r->wf_fin_counters[set]; prm.rgba = rgba; prm.hit_t_aov = nullptr; prm.point_rgb = point;
     prm.import_gen = gen; prm.imp_n_seg = B.n_seg; prm.imp_seg_cap = B.seg_cap; prm.imp_ray_cap = B.ray_cap;
-    prm.imp_ray_od = B.ray_od[gen & 1u]; prm.imp_ray_parent = B.ray_parent[gen & 1u]; prm.imp_ray_aux = B.ray_aux[gen & 1u];
+    prm.imp_ray = B.ray[gen & 1u]; prm.imp_ray_pa = B.ray_pa[gen & 1u];
     prm.imp_seg_count = B.seg_count + (size_t)gen * B.n_seg; prm.imp_seg_count_rows = B.seg_count;
     prm.stats_counters = r->d_counters;
     HIP_TRY(hipMemsetAsync(r->wf_fin_counters[set], 0, sizeof(EuDevCounters), stream));

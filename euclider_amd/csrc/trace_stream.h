@@ -219,8 +219,9 @@ struct EuTsParams {
     eu_f64 *hit_t_aov, *point_rgb;
     /* import mode (import_gen != 0xffffffff): the wavefront pipeline's queue of that generation */
     uint32_t import_gen, imp_n_seg, imp_seg_cap, imp_ray_cap;
-    const double *imp_ray_od;
-    const uint32_t *imp_ray_parent, *imp_ray_aux, *imp_seg_count;
+    const double *imp_ray;            /* the wavefront queue's records (EuWfRay<D>, trace_wavefront.h) */
+    const uint2 *imp_ray_pa;
+    const uint32_t *imp_seg_count;
     uint32_t *imp_seg_count_rows;      /* the pipeline's [EU_MAX_DEPTH + 1][n_seg] table: rows behind import_gen are cleared (they describe an older frame) */
     EuDevCounters *stats_counters;     /* not null: add rays / background samples / would-panic counts (and an abort) to the pipeline's accounting */
 };
@@ -346,14 +347,15 @@ template <int D> EU_DEV void ts_import(TsState &st) {
     const EuTsPool P = ts_pool(q);
     const uint32_t i = st.imp_off + tid;
     const bool have = i < st.imp_count;
-    const size_t cap = q->imp_ray_cap, slot = (size_t)st.cur_tile * q->imp_seg_cap + i;
+    const size_t slot = (size_t)st.cur_tile * q->imp_seg_cap + i;
     double o[D], d[D];
     uint32_t parent = 0, aux = 0;
     if (have) {
-        const double *od = q->imp_ray_od;
+        const double *od = q->imp_ray + slot * (size_t)(2 * D);
 #pragma unroll
-        for (int k = 0; k < D; k++) { o[k] = od[(size_t)k * cap + slot]; d[k] = od[(size_t)(D + k) * cap + slot]; }
-        parent = q->imp_ray_parent[slot]; aux = q->imp_ray_aux[slot];
+        for (int k = 0; k < D; k++) { o[k] = od[k]; d[k] = od[D + k]; }
+        const uint2 pa = q->imp_ray_pa[slot];
+        parent = pa.x; aux = pa.y;
     }
     uint32_t second;
     const uint32_t pos = ts_reserve(&st.app_pos, have ? 1u : 0u, second);

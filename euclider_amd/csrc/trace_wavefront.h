@@ -61,13 +61,22 @@
 #endif
 
 
+/* Queue records are arrays of structures: a ray is ONE 2D-value record, its hit ONE 16-byte record.  As structure of arrays (one
+ * stream per component: 6 + 2 + 3 streams for D = 3) every vector memory instruction of a ray batch went to a different page, 1.5 MB
+ * further on than in the batch before, and ISSUING the six component loads took a wave 16 K cycles per batch (`-DEU_PROFILE_SHAPE`: 41 %
+ * of the generation-0 intersect kernel; with the same bytes from consecutive words: 11 %). */
+template <int D> struct alignas(2 * sizeof(double)) EuWfRay { double o[D], d[D]; };
+struct alignas(16) EuWfHit {
+    double t; uint32_t code, ent;      /* ent 0xffffffff: nothing hit */
+#if EU_REAL_BITS == 32
+    uint32_t pad;
+#endif
+};
+static_assert(sizeof(EuWfHit) == 16, "one 16-byte store per ray");
 struct EuWfBuffers {
-    double *ray_od[2];          /* [2*D][ray_cap] origin then direction, component-major; ping-pong by generation */
-    uint32_t *ray_parent[2];    /* node id that receives this ray's colour */
-    uint32_t *ray_aux[2];       /* entity the ray travels in (bits 0..15) | child slot in the parent (bit 16) */
-    double *hit_t;              /* per ray of the current generation */
-    uint32_t *hit_code;
-    uint32_t *hit_ent;          /* 0xffffffff: nothing hit */
+    double *ray[2];             /* [ray_cap] EuWfRay<D>: origin then direction; ping-pong by generation */
+    uint2 *ray_pa[2];           /* x: node id that receives this ray's colour; y: entity the ray travels in (bits 0..15) | delivery slot / mode (bits 16..18) */
+    EuWfHit *hit;               /* per ray of the current generation */
     /* tree nodes (trace_nodes.h): one id per traced ray in queue order, only the slots of rays that need one are touched */
     EuTsNode *nodes;            /* [node_cap] */
     uint8_t *node_kind;         /* [node_cap] TS_NONE / TS_OVER / ...: what resolve has to do for the ray in this slot */
@@ -154,10 +163,16 @@ EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_
 struct WfRay { uint32_t q; };
 
 template <int D> EU_DEV void wf_store_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, const double *o, const double *d, uint32_t parent, uint32_t aux) {
+    EuWfRay<D> r;
 #pragma unroll
-    for (int k = 0; k < D; k++) { B.ray_od[buf][(size_t)k * B.ray_cap + q] = o[k]; B.ray_od[buf][(size_t)(D + k) * B.ray_cap + q] = d[k]; }
-    B.ray_parent[buf][q] = parent;
-    B.ray_aux[buf][q] = aux;
+    for (int k = 0; k < D; k++) { r.o[k] = o[k]; r.d[k] = d[k]; }
+    ((EuWfRay<D> *)B.ray[buf])[q] = r;
+    B.ray_pa[buf][q] = make_uint2(parent, aux);
+}
+template <int D> EU_DEV void wf_load_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, double *o, double *d) {
+    const EuWfRay<D> r = ((const EuWfRay<D> *)B.ray[buf])[q];
+#pragma unroll
+    for (int k = 0; k < D; k++) { o[k] = r.o[k]; d[k] = r.d[k]; }
 }
 
 /* ------------------------------------------------------------------ primary rays */
@@ -304,8 +319,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
         for (int k = 0; k < D; k++) { o_next[k] = R(0.0); d_next[k] = R(0.0); }
         if (v < total) {
             i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v);
-#pragma unroll
-            for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+            wf_load_ray<D>(B, in, i_next, o_next, d_next);
         }
         for (; v < total; v += v_step) {
             IS_START();
@@ -316,8 +330,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
 #if EU_ISECT_PREFETCH
             if (v + v_step < total) {
                 i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
-#pragma unroll
-                for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+                wf_load_ray<D>(B, in, i_next, o_next, d_next);
             }
 #endif
             cnt.rays++;
@@ -383,14 +396,18 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
 #if !EU_ISECT_PREFETCH      /* (123 instead of 137 VGPRs; measured equal) */
             if (v + v_step < total) {
                 i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
-#pragma unroll
-                for (int k = 0; k < D; k++) { o_next[k] = B.ray_od[in][(size_t)k * B.ray_cap + i_next]; d_next[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i_next]; }
+                wf_load_ray<D>(B, in, i_next, o_next, d_next);
             }
 #endif
-            B.hit_t[i] = best_t;
-            B.hit_code[i] = best_code;
-            B.hit_ent[i] = best_ent;
-            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_parent[0][i]] = have ? best_t : -R(1.0);      /* a primary ray's parent is its pixel */
+            {
+                EuWfHit h;
+                h.t = best_t; h.code = best_code; h.ent = best_ent;
+#if EU_REAL_BITS == 32
+                h.pad = 0;
+#endif
+                B.hit[i] = h;
+            }
+            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_pa[0][i].x] = have ? best_t : -R(1.0);      /* a primary ray's parent is its pixel */
             IS_STAMP(15);
         }
     }
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
                 if (v < wbase + win && v < total) {
                     myq[k] = wf_map_index(pref, B.n_seg, B.seg_cap, v);
-                    const uint32_t he = B.hit_ent[myq[k]];
+                    const uint32_t he = B.hit[myq[k]].ent;
                     mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
                     myrank[k] = atomicAdd(&hist[mykey[k]], 1u);
                 }
@@ -488,13 +505,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             bool bg_miss = false;
             if (live) {
                 WF_STAMP(1);
-                const uint32_t parent = B.ray_parent[in][i];
-                const uint32_t aux = B.ray_aux[in][i];
+                const uint2 pa = B.ray_pa[in][i];
+                const uint32_t parent = pa.x, aux = pa.y;
                 const uint32_t ent = aux & 0xffffu, sm = (aux >> 16) & 7u;
                 double o[D], d[D];
-#pragma unroll
-                for (int k = 0; k < D; k++) { o[k] = B.ray_od[in][(size_t)k * B.ray_cap + i]; d[k] = B.ray_od[in][(size_t)(D + k) * B.ray_cap + i]; }
-                const uint32_t hit_ent = B.hit_ent[i];
+wf_load_ray<D>(B, in, i, o, d);
+                const EuWfHit hit = B.hit[i];
+                const uint32_t hit_ent = hit.ent;
                 uint32_t node_kind = TS_NONE;
                 if (hit_ent == 0xffffffffu) {
                     /* nothing hit: the background colour goes to the parent; handled as a depth-0 "child" below */
@@ -503,8 +520,8 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                     c_parent[0] = parent; c_sm[0] = sm;
                     n_child = 1; bg_miss = true;
                 } else {
-                    const double best_t = B.hit_t[i];
-                    const uint32_t best_code = B.hit_code[i];
+                    const double best_t = hit.t;
+                    const uint32_t best_code = hit.code;
                     HitCtx<D> c;
                     c.finish(best_t, o, d);
                     hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
