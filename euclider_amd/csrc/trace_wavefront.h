@@ -147,15 +147,19 @@ EU_DEV uint32_t wf_build_prefix(const uint32_t *seg_count, uint32_t n_seg, uint3
     for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
     uint32_t run = base + inc - s;                     /* exclusive prefix of this thread's first element */
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = t * 4 + k; if (idx < n_seg) pref[idx] = run; run += v[k]; }
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = t * 4 + k; if (idx < n_seg) pref[idx] = run; else if (idx > n_seg) pref[idx] = 0xffffffffu; run += v[k]; }
     const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    if (t == 0) pref[n_seg] = total;
+    if (t == 0) pref[n_seg] = total;      /* (entries behind n_seg: sentinels for wf_map_index, which reads indices < EU_WF_MAX_SEG only) */
     __syncthreads();
     return total;
 }
+/* queue slot of ray number v < total: the largest seg with pref[seg] <= v, found with a fixed number of steps and no branch (the table
+ * is padded with 0xffffffff up to EU_WF_MAX_SEG: half the instructions of a bisection loop with its exit test, once per ray) */
 EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_cap, uint32_t v) {
-    uint32_t lo = 0, hi = n_seg;                       /* largest seg with pref[seg] <= v */
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= v) lo = mid; else hi = mid; }
+    static_assert((EU_WF_MAX_SEG & (EU_WF_MAX_SEG - 1)) == 0, "power of two");
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = EU_WF_MAX_SEG / 2; step != 0; step >>= 1) lo += pref[lo + step] <= v ? step : 0u;
     return lo * seg_cap + (v - pref[lo]);
 }
 
