@@ -321,9 +321,17 @@ template <int D> struct FrameStack {
     double data[EU_MAX_DEPTH][2 * D];
 };
 
-#ifdef EU_PROFILE_SHAPE      /* diagnostic build: s_memtime shares of eval_shape's parts -> EuDevCounters::phase[] (tools/shape_profile.py) */
-struct LaneCounters { uint32_t rays, bg, nan_px, errors; unsigned long long ph[8], last; };
-#define SHP(c, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (c).ph[(k)] += now_ - (c).last; (c).last = now_; } while (0)
+#ifdef EU_PROFILE_SHAPE      /* diagnostic build: s_memtime shares of eval_shape's parts -> EuDevCounters::phase[] (tools/shape_profile.py).
+                              * The sums live in LDS, one row per wave, and are advanced by the first ACTIVE lane at each stamp: a per-lane copy
+                              * would book the time a lane sits masked off to whatever region it wakes up in. */
+struct LaneCounters { uint32_t rays, bg, nan_px, errors; unsigned long long *prof; };      /* prof: [16 sums][last] of this wave */
+#ifdef EU_PROFILE_SHAPE_LANES  /* the same shares weighted with the lanes active at the stamp (x / 64 on the host): where the idle lanes are */
+#define SHP_W_ ((unsigned long long)__builtin_popcountll(m_))
+#else
+#define SHP_W_ 1ull
+#endif
+#define SHP(c, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); const unsigned long long m_ = __ballot(1); \
+    if ((c).prof && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_)) { (c).prof[(k)] += (now_ - (c).prof[16]) * SHP_W_; (c).prof[16] = now_; } } while (0)
 #else
 struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
 #define SHP(c, k) do { } while (0)

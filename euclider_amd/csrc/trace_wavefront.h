@@ -103,7 +103,7 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
     }
     __syncthreads();
 #ifdef EU_PROFILE_SHAPE
-    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) if (cnt.ph[q]) atomicAdd(&counters->phase[q], cnt.ph[q]);
+    if ((threadIdx.x & 63) == 0 && cnt.prof) for (int q = 0; q < 16; q++) if (cnt.prof[q]) atomicAdd(&counters->phase[q], cnt.prof[q]);
 #endif
     if (threadIdx.x == 0) {
         if (wg_cnt[0]) atomicAdd(&counters->rays, wg_cnt[0]);
@@ -297,8 +297,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
     }
     LaneCounters cnt = {0, 0, 0, 0};
 #ifdef EU_PROFILE_SHAPE
-    for (int q = 0; q < 8; q++) cnt.ph[q] = 0;
-    cnt.last = __builtin_amdgcn_s_memtime();
+    __shared__ unsigned long long prof_rows[EU_WF_BLOCK / 64][17];
+    cnt.prof = prof_rows[threadIdx.x >> 6];
+    if ((threadIdx.x & 63) < 16) cnt.prof[threadIdx.x & 63] = 0;
+    if ((threadIdx.x & 63) == 16) cnt.prof[16] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_wave_barrier();
 #endif
 #ifdef EU_PROFILE_ISECT       /* diagnostic build: cycles per entity slot (phase[e], e < 14), ray load (14), result store (15) */
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
     const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    SHP(cnt, 8);      /* kernel prologue: scene header, queue prefix */
     {
         /* software pipeline: the next ray of this lane is located and its loads are issued before the current one is
          * intersected (the kernel keeps 3 waves per SIMD: too few to hide an HBM round trip behind other waves) */
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
             }
 #endif
             cnt.rays++;
+            SHP(cnt, 9);      /* per batch: current ray out of the prefetch registers, next ray located and requested */
 #ifdef EU_EXP_DUMMY_VALU      /* experiment ("what an instruction costs"): EU_EXP_DUMMY_VALU extra f64 VALU instructions per ray batch, 4 independent chains */
             {
                 double a0 = o[0], a1 = o[1], a2 = d[0], a3 = d[1];
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
                 B.hit[i] = h;
             }
             if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_pa[0][i].x] = have ? best_t : -R(1.0);      /* a primary ray's parent is its pixel */
+            SHP(cnt, 10);     /* per batch: entity loop's end, result store */
             IS_STAMP(15);
         }
     }

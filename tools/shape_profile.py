@@ -17,9 +17,10 @@ env.camera.max_depth = depth
 img = env.render((w, h))
 ph = (C.c_uint64 * 16)()
 _capi.lib().eu_renderer_debug_phases(env.renderer(0), ph)
-tot = float(sum(ph[:8])) or 1.0
+tot = float(sum(ph[:12])) or 1.0
 print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"])
 names = ["chain: bound test, set-up", "chain: matrices (t_k, IN, LT)", "chain: merge cascade", "chain: push to the hit stack", "leaf ops",
-         "composite merges (incl. inside tests)", "outside eval_shape's ops (ray load, entity loop, entity bound test, result)", "top-level Union chain: first element directly"]
-for i in range(8):
-    print("  %-78s %6.2f%%" % (names[i], 100.0 * ph[i] / tot))
+         "composite merges (incl. inside tests)", "entity loop between the ops (entity record, bounding-sphere test, root op, result selection)", "top-level Union chain: first element directly",
+         "kernel prologue (scene header, queue prefix)", "per batch: ray out of the prefetch registers, next ray located and requested", "per batch: end of the entity loop, result store", "-"]
+for i in range(11):
+    print("  %-78s %6.2f%%  %10.1f M" % (names[i], 100.0 * ph[i] / tot, ph[i] / 1e6))
