@@ -38,7 +38,12 @@ enum EuShapeKind : uint32_t {
      * +-0) and a finite non-zero constant: what HalfSpace3::cuboid / HalfSpace4::hypercuboid build (d3/entity/shape.rs:17-66).
      * Same semantics as EU_SH_CHAIN_INTERSECTION; the device may replace every dot product with the normal by one
      * multiplication (trace_device.h, chain_matrices_box). */
-    EU_SH_CHAIN_BOX = 18
+    EU_SH_CHAIN_BOX = 18,
+    /* Not a shape: a guard in front of a bounded composite subtree that is not an entity's root (the loader puts one where the
+     * subtree's bounding sphere is clearly smaller than its parent's).  `first` holds the index of the subtree's root op, `param` its
+     * entry in the bounds table.  A wave whose rays all miss the sphere pushes an empty list and continues behind the root op (the
+     * subtree's stream is empty: same argument as for an entity's bound); the containment test does the same for points outside. */
+    EU_SH_SKIP = 24
 };
 #define EU_CHAIN_MAX 8
 enum EuMaterialKind : uint32_t { EU_MAT_VACUUM = 0, EU_MAT_LINEAR = 1 };

@@ -773,7 +773,8 @@ struct Flattener {
     }
 
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
-    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false) {
+    static bool no_guards() { static const bool v = getenv("EU_NO_SKIP_OPS") != nullptr; return v; }      /* A/B diagnostics */
+    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false, double parent_r = INFINITY) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
         op.first = (uint16_t)ops.size();
@@ -803,8 +804,26 @@ struct Flattener {
             if (use > hit_cap) hit_cap = use;
             if (depth + 1 > list_depth) list_depth = depth + 1;
         } else if (s.kind == Shape::ComposableShape) {
-            uint32_t la = emit_shape(*s.sa, base_use, depth);
-            uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1);
+            /* a bounded subtree whose sphere is clearly smaller than what encloses it gets a guard op in front (EU_SH_SKIP) */
+            const Bound sb_ = shape_bound(s);
+            const bool has_b = sb_.ok && sb_.r > R(0.0) && std::isfinite(sb_.r);
+            size_t skip_at = (size_t)-1;
+            if (!is_root && has_b && !no_guards() && sb_.r < R(0.7) * parent_r) {
+                const uint32_t id = register_bound(sb_);
+                if (id != 0xffffffffu) {
+                    skip_at = ops.size();
+                    EuShapeOp sk{};
+                    sk.kind = (uint8_t)EU_SH_SKIP; sk.param = id;
+                    ops.push_back(sk);
+                }
+            }
+            const double child_r = has_b ? std::min(parent_r, (double)sb_.r) : parent_r;
+            uint32_t la = emit_shape(*s.sa, base_use, depth, false, child_r);
+            uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1, false, child_r);
+            if (skip_at != (size_t)-1) {
+                if (ops.size() >= 65535) fail(ParserError::CustomError, "too many shape nodes");
+                ops[skip_at].first = (uint16_t)ops.size();        /* index the subtree's root op is about to get */
+            }
             /* a Complement may hand out `a` once more without consuming it (shape.rs:390-392): one element more than it
              * consumed.  At an entity's root only element 0 is ever looked at, so the extra slot is not reserved there. */
             const uint32_t extra = s.operation == SetOperation::Complement ? 1u : 0u;
@@ -891,6 +910,45 @@ struct Flattener {
         return o;
     }
 
+    /* Intersection tree of ONE infinite cylinder with half-spaces whose normals are parallel to its axis and that cut it on both
+     * sides (Cylinder::new_with_height, shape.rs:906-927): centre on the axis between the caps, radius^2 = r^2 + (half length)^2 */
+    static void intersection_leaves(const Shape &s, std::vector<const Shape *> &out) {
+        if (s.kind == Shape::ComposableShape && s.operation == SetOperation::Intersection) { intersection_leaves(*s.sa, out); intersection_leaves(*s.sb, out); }
+        else out.push_back(&s);
+    }
+    Bound capped_cylinder_bound(const Shape &s) const {
+        Bound o;
+        std::vector<const Shape *> leaves;
+        intersection_leaves(s, leaves);
+        const Shape *cyl = nullptr;
+        for (auto *l : leaves) { if (l->kind == Shape::Cylinder) { if (cyl) return o; cyl = l; } else if (l->kind != Shape::HalfSpace) return o; }
+        if (!cyl || !(cyl->r > R(0.0)) || !std::isfinite(cyl->r)) return o;
+        double u[MAXD], un = R(0.0);
+        for (int i = 0; i < D; i++) un += cyl->b[i] * cyl->b[i];
+        un = sqrt(un);
+        if (!(un > R(0.0)) || !std::isfinite(un)) return o;
+        for (int i = 0; i < D; i++) u[i] = cyl->b[i] / un;
+        bool has_lo = false, has_hi = false; double lo = R(0.0), hi = R(0.0);
+        for (auto *l : leaves) {
+            if (l == cyl) continue;
+            if (!(l->signum == R(1.0) || l->signum == -R(1.0))) return o;
+            double k1 = R(0.0), k0 = l->r, nn = R(0.0);
+            for (int i = 0; i < D; i++) { k1 += l->a[i] * u[i]; k0 += l->a[i] * cyl->a[i]; nn += l->a[i] * l->a[i]; }
+            double perp2 = nn - k1 * k1;                          /* the normal's part across the axis */
+            if (!(nn > R(0.0)) || !(perp2 <= R(1.0e-18) * nn) || k1 == R(0.0)) continue;      /* not a cap: ignored (it can only cut more away) */
+            const double edge = -k0 / k1;                          /* inside <=> sign(k0 + k1 * tau) == signum */
+            if (!std::isfinite(edge)) continue;
+            if (l->signum * k1 > R(0.0)) { if (!has_lo || edge > lo) lo = edge; has_lo = true; }
+            else { if (!has_hi || edge < hi) hi = edge; has_hi = true; }
+        }
+        if (!has_lo || !has_hi || !(hi > lo)) return o;
+        const double mid = (lo + hi) / R(2.0), half = (hi - lo) / R(2.0);
+        for (int i = 0; i < D; i++) o.c[i] = cyl->a[i] + u[i] * mid;
+        o.r = sqrt(cyl->r * cyl->r + half * half);
+        o.ok = std::isfinite(o.r);
+        return o;
+    }
+
     Bound shape_bound(const Shape &s) const {
         Bound o;
         switch (s.kind) {
@@ -903,6 +961,7 @@ struct Flattener {
             if (s.operation == SetOperation::Intersection) {
                 std::vector<const Shape *> chain;
                 if (collect_chain(s, SetOperation::Intersection, chain)) { Bound b = box_bound(chain); if (b.ok) return b; }
+                { Bound cb = capped_cylinder_bound(s); if (cb.ok) return cb; }
                 Bound a = shape_bound(*s.sa), b = shape_bound(*s.sb);
                 if (a.ok && b.ok) return a.r <= b.r ? a : b;
                 return a.ok ? a : b;
@@ -914,8 +973,8 @@ struct Flattener {
         }
     }
 
-    uint32_t entity_bound(const Shape &s) {
-        Bound b = shape_bound(s);
+    uint32_t entity_bound(const Shape &s) { return register_bound(shape_bound(s)); }
+    uint32_t register_bound(const Bound &b) {
         if (!b.ok || !(b.r > R(0.0))) return 0xffffffffu;
         double cmax = R(0.0);
         for (int i = 0; i < D; i++) { if (!std::isfinite(b.c[i])) return 0xffffffffu; cmax = std::max(cmax, fabs(b.c[i])); }
@@ -1062,7 +1121,10 @@ FlatScene flatten(const Universe &u) {
         uint32_t before_cap = f.hit_cap;
         f.hit_cap = 0;
         fe.shape_first = (uint16_t)f.ops.size();
-        f.emit_shape(*e->shape, 0, 0, true);
+        {
+            const auto eb = f.shape_bound(*e->shape);
+            f.emit_shape(*e->shape, 0, 0, true, eb.ok && eb.r > R(0.0) ? (double)eb.r : (double)INFINITY);
+        }
         fe.shape_root = (uint16_t)(f.ops.size() - 1);
         fe.max_hits = f.hit_cap;
         fe.bound = e->surface ? f.entity_bound(*e->shape) : 0xffffffffu;
@@ -1101,6 +1163,8 @@ FlatScene flatten(const Universe &u) {
     h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
     h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * sizeof(f.bounds[0]));
     h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
+    /* flags bit 1: some shape program holds guard ops (EU_SH_SKIP) */
+    for (auto &o : f.ops) if (o.kind == EU_SH_SKIP) { h.flags |= 2u; break; }
     /* flags bit 0: some surface can spawn BOTH a transmission and a reflection ray (ratio strictly between 0 and 1
      * possible): the recursion tree branches and a frame holds several times more rays than pixels */
     for (auto &fs : f.surfaces)

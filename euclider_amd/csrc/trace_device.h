@@ -67,6 +67,7 @@ struct EuScene {
     const uint64_t *wrt;    /* the blob in device memory: texel addresses are patched there at upload */
     uint32_t off_ops, off_params, off_entities, n_entities, off_materials, off_transforms, off_code;
     uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background, off_bounds;
+    uint32_t has_skip;      /* header flags bit 1: some shape program holds guard ops (EU_SH_SKIP) */
 
     EU_DEV void init(const uint64_t *base) {
         w = base; wrt = base;
@@ -75,6 +76,7 @@ struct EuScene {
         off_materials = h->off_materials; off_transforms = h->off_transforms; off_code = h->off_code;
         off_surfaces = h->off_surfaces; off_color_ops = h->off_color_ops; off_mapped = h->off_mapped;
         off_perlin = h->off_perlin; background = h->background; off_bounds = h->off_bounds;
+        has_skip = h->flags & 2u;
     }
     EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
     EU_DEV eu_f64 dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
@@ -271,6 +273,17 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, cnt;
         S.op(i, kind, f, param, cnt);
+        if (kind == EU_SH_SKIP) {      /* guard of the bounded subtree ending at op f: a point outside its (enlarged) bounding sphere is in none of its leaves'
+                                        * solids by a margin that dwarfs rounding; the walk stays wave-uniform, so the subtree is skipped only if no lane needs it */
+            if (f <= root) {           /* (a guard whose subtree reaches beyond `root` belongs to an enclosing subtree: not ours) */
+                const double *Bd = S.bounds(param, D);
+                double rr = R(0.0);
+#pragma unroll
+                for (int m = 0; m < D; m++) { const double q = p[m] - Bd[m]; rr = rr + q * q; }
+                if (__ballot(!(rr > Bd[D])) == 0ull) { st <<= 1; i = f; }
+            }
+            continue;
+        }
         if (kind == EU_SH_CHAIN_BOX) {
             st = (st << 1) | (chain_inside_box<D>(S.params(param), p) ? 1ull : 0ull);
         } else if (kind >= EU_SH_CHAIN_UNION) {
@@ -645,6 +658,10 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, count;
         S.op(i, kind, f, param, count);
+        if (kind == EU_SH_SKIP) {      /* guard of the bounded subtree ending at op f (flat_scene.h): every ray of the wave misses its sphere -> its stream is empty */
+            if (__ballot(!ray_misses_bound<D>(S.bounds(param, D), o, d)) == 0ull) { lens <<= 8; unk <<= 1; i = f; }
+            continue;
+        }
         if (kind >= EU_SH_CHAIN_UNION) {
             double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
             const double *Pc = S.params(param);
@@ -691,7 +708,13 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
         uint32_t kb, fb, pb, cb_;
         S.op(i - 1, kb, fb, pb, cb_);
-        const uint32_t ra = fb - 1, fa = f, rb = i - 1;
+        uint32_t fa = f;
+        if (S.has_skip) {   /* this subtree's own guard op, if it has one, sits at f: it is not part of child a */
+            uint32_t k0, f0, p0, c0;
+            S.op(f, k0, f0, p0, c0);
+            if (k0 == EU_SH_SKIP && f0 == i) fa = f + 1;
+        }
+        const uint32_t ra = fb - 1, rb = i - 1;
         const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
         lens >>= 16;
         const bool unk_b = (unk & 1u) != 0, unk_a = (unk & 2u) != 0;

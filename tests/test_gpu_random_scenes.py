@@ -104,3 +104,68 @@ def test_random_scene_parity_many_entities(seed, n):
     """Scenes far larger than the shipped ones: the flat scene no longer fits the shade kernel's LDS copy (global variant), the
     sort keys of entities >= 31 share a bucket, hundreds of bounds and materials."""
     run_case(seed, 64, 48, 4, n_entities=n, min_flat_bytes=45 * 1024 if n >= 150 else 0)
+
+
+def test_guarded_subtrees_parity():
+    """Capped cylinders and spheres far apart inside Unions and a Complement: the loader guards the bounded subtrees (EU_SH_SKIP,
+    tests/test_loader.py::test_bounded_subtrees_get_guard_ops), waves whose rays all miss a guard's sphere jump over the subtree, and
+    containment tests of points outside it are answered by the sphere.  Reflective surfaces send the rays round the scene, the
+    camera stands between the solids.  Must equal the oracle, which knows nothing of guards."""
+    import json
+    from euclider_amd import Parser
+    from oracle.scene_loader import OracleScene, default_texture_loader
+
+    def cyl(c, d, h=4):
+        return {"Cylinder3::new_with_height": [{"Point3::new": c}, {"Vector3::new": d}, 0.5, h]}
+
+    def sph(c, r=1.0):
+        return {"Sphere3::new": [{"Point3::new": c}, r]}
+
+    def of(shapes, op):
+        return {"ComposableShape3::of": [shapes, {"SetOperation": [op]}]}
+
+    def entity(shape, ratio):
+        return {"Entity3Impl::new_with_surface": [shape, {"Vacuum3::new": []}, {"ComposableSurface3": {
+            "reflection_ratio": {"reflection_ratio_uniform_3": [ratio]},
+            "reflection_direction": {"reflection_direction_specular_3": []},
+            "threshold_direction": {"threshold_direction_identity_3": []},
+            "surface_color": {"surface_color_illumination_directional_3": [{"Vector3::new": [0.3, -0.5, -1]}, {"Rgba::new": [1, 0.8, 0.6, 1]}, {"Rgba::new": [0.1, 0.1, 0.3, 1]}]}}}]}
+
+    shapes = [
+        of([cyl([6, 3, 0], [1, 0, 0]), cyl([6, -3, 1], [0, 0, 1]), sph([9, 0, -2]), cyl([5, 0, 3], [0, 1, 0], 6)], "Union"),
+        of([of([sph([-6, 2, 0], 2.0), sph([-6, -3, 0], 1.5)], "Union"), of([cyl([-6, 2, 0], [0, 0, 1], 6), sph([-6, -3, 1], 1.0)], "Union")], "Complement"),
+        of([of([sph([0, 7, 0], 1.5), cyl([0, 7, 0], [1, 1, 0], 5)], "SymmetricDifference"), sph([0, -7, 0], 2.0)], "Union"),
+    ]
+    text = json.dumps({"Universe3": {"camera": {"FreeCamera3": []},
+                                     "entities": [entity(s, r) for s, r in zip(shapes, (0.5, 0.3, 0.0))] + [{"Void3::new_with_vacuum": []}],
+                                     "background": {"MappedTextureImpl3::new": [{"uv_sphere_3": [{"Point3::new": [0, 0, 0]}]},
+                                                                               {"texture_image_nearest_neighbor": ["./resources/simple.png"]}]}}})
+    env = Parser(texture_dirs=[ROOT]).parse(text)
+    assert env.info.n_shape_ops > 30          # guards included
+    env.camera.max_depth = 6
+    osc = OracleScene(text, default_texture_loader([ROOT]))
+    for fwd in ([1.0, 0.0, 0.0], [-1.0, 0.2, 0.1], [0.1, 1.0, 0.0]):
+        import math
+        n = math.sqrt(sum(x * x for x in fwd))
+        for k in range(3):
+            env.camera.forward[k] = fwd[k] / n
+        # left = up x forward with up = z, kept orthonormal enough for a picture; the oracle gets the same pose
+        left = [-env.camera.forward[1], env.camera.forward[0], 0.0]
+        ln = math.sqrt(sum(x * x for x in left)) or 1.0
+        for k in range(3):
+            env.camera.left[k] = left[k] / ln
+        up = [env.camera.forward[1] * env.camera.left[2] - env.camera.forward[2] * env.camera.left[1],
+              env.camera.forward[2] * env.camera.left[0] - env.camera.forward[0] * env.camera.left[2],
+              env.camera.forward[0] * env.camera.left[1] - env.camera.forward[1] * env.camera.left[0]]
+        for k in range(3):
+            env.camera.up[k] = up[k]
+        ocam = osc.camera()
+        for fld in ("location", "forward", "up", "left"):
+            for k in range(3):
+                getattr(ocam, fld)[k] = getattr(env.camera, fld)[k]
+        img = env.render((160, 90), want_hit_t=True)
+        orgb, ohit, ost = osc.render(160, 90, max_depth=6, want_hit_t=True, camera=ocam)
+        assert np.array_equal(img.data, orgb) and img.stats == ost
+        both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
+        assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan])
+    env.close()

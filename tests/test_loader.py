@@ -72,6 +72,44 @@ def test_cuboid_is_collapsed_to_a_half_space_chain():
     env.close()
 
 
+def _flat_ops(env):
+    """(kind, first, param) of every shape op of the flattened scene (flat_scene.h), header flags."""
+    import ctypes as C
+    import struct
+    from euclider_amd import _capi
+    L = _capi.lib()
+    L.eu_scene_flat.restype = C.c_void_p
+    n = C.c_size_t()
+    raw = C.string_at(L.eu_scene_flat(env._scene, C.byref(n)), n.value)
+    h = struct.unpack("<32I", raw[:128])
+    n_ops, off_ops, flags = h[4], h[5], h[27]
+    words = struct.unpack("<%dQ" % n_ops, raw[off_ops * 8:(off_ops + n_ops) * 8])
+    return [(w & 0xff, (w >> 16) & 0xffff, w >> 32) for w in words], flags
+
+
+def test_bounded_subtrees_get_guard_ops():
+    """A capped cylinder (Cylinder::new_with_height = cylinder with two half-spaces, shape.rs:906-927) inside a Union is bounded:
+    the loader recognises it and puts a guard op (EU_SH_SKIP = 24) in front of its five ops; `first` of the guard is the index of the
+    subtree's root op.  An entity's own root never gets one (the entity record carries that bound)."""
+    cyl = lambda c, d: {"Cylinder3::new_with_height": [{"Point3::new": c}, {"Vector3::new": d}, 0.5, 4]}
+    union = {"ComposableShape3::of": [[cyl([0, 8, 0], [1, 0, 0]), cyl([0, -8, 0], [0, 0, 1]), {"Sphere3::new": [{"Point3::new": [9, 0, 0]}, 1]}],
+                                      {"SetOperation": ["Union"]}]}
+    env = Parser().parse(universe([entity(union)]))
+    ops, flags = _flat_ops(env)
+    kinds = [k for k, _, _ in ops]
+    assert kinds.count(24) == 2 and flags & 2
+    for i, (k, first, _) in enumerate(ops):
+        if k == 24:
+            assert first == i + 5 and ops[first][0] == 9          # cylinder, half-space, Intersection, half-space, Intersection (root)
+            assert ops[first][1] == i                              # the guarded subtree starts at its guard
+    assert ops[-1][0] == 8 and kinds[0] == 24                      # the entity's root Union itself is not guarded
+    env.close()
+    lone = Parser().parse(universe([entity(cyl([0, 0, 0], [0, 0, 1]))]))
+    ops, flags = _flat_ops(lone)
+    assert 24 not in [k for k, _, _ in ops] and not (flags & 2)    # entity root: bound in the entity record instead
+    lone.close()
+
+
 @pytest.mark.parametrize("text,kind", [
     ("{ not json", "SyntaxError"),
     (json.dumps({"Universe3": {}, "Universe4": {}}), "InvalidConstructor"),
