@@ -39,6 +39,10 @@ enum EuShapeKind : uint32_t {
      * Same semantics as EU_SH_CHAIN_INTERSECTION; the device may replace every dot product with the normal by one
      * multiplication (trace_device.h, chain_matrices_box). */
     EU_SH_CHAIN_BOX = 18,
+    /* the same with at least one constant that is +-0 (a face through a coordinate plane): the one-product form differs from the dot
+     * product only when the product with the normal's +-1 component is -0 next to a zero constant; the device watches for exactly that
+     * (chain_matrices_box<D, true>) */
+    EU_SH_CHAIN_BOX0 = 19,
     /* Not a shape: a guard in front of a bounded composite subtree that is not an entity's root (the loader puts one where the
      * subtree's bounding sphere is clearly smaller than its parent's).  `first` holds the index of the subtree's root op, `param` its
      * entry in the bounds table.  A wave whose rays all miss the sphere pushes an empty list and continues behind the root op (the
@@ -88,7 +92,7 @@ struct EuFlatHeader {
  *   CYLINDER  c[D], axis[D] (normalised), r, r*r                                           */
 struct EuShapeOp {
     uint8_t kind;
-    uint8_t count;       /* chain ops: number of leaves (2..EU_CHAIN_MAX) */
+    uint8_t count;       /* chain ops: number of leaves (2..EU_CHAIN_MAX); composite ops: 1 if the subtree's first op is its guard (EU_SH_SKIP) */
     uint16_t first;      /* index (within the ops table) of the first op of this subtree */
     uint32_t param;      /* word offset into the params table */
 };

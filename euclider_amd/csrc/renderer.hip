@@ -271,10 +271,11 @@ static int make_dev_camera(const eu_camera *cam, const eu_frame *f, EuDevCamera 
     memset(&dc, 0, sizeof dc);
     for (int i = 0; i < D; i++) { dc.location[i] = cam->location[i]; dc.forward[i] = cam->forward[i]; dc.up[i] = cam->up[i]; }
     if (D == 3) {   /* get_right = cross(forward, up).normalize(), d3/entity/camera.rs:62-64 */
-        double cr[3];
-        cr[0] = cam->forward[1] * cam->up[2] - cam->forward[2] * cam->up[1];
-        cr[1] = cam->forward[2] * cam->up[0] - cam->forward[0] * cam->up[2];
-        cr[2] = cam->forward[0] * cam->up[1] - cam->forward[1] * cam->up[0];
+        double cr[3];      /* from the pose already rounded to F: the reference's camera holds F values (with the ABI's f64 fields
+                             * the low_precision build used to form these products in f64: one ulp off for a pose that is not f32-exact) */
+        cr[0] = dc.forward[1] * dc.up[2] - dc.forward[2] * dc.up[1];
+        cr[1] = dc.forward[2] * dc.up[0] - dc.forward[0] * dc.up[2];
+        cr[2] = dc.forward[0] * dc.up[1] - dc.forward[1] * dc.up[0];
         double n = sqrt((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
         for (int i = 0; i < 3; i++) dc.right[i] = cr[i] / n;
     } else {        /* right = -left, d4/entity/camera.rs:167 */

@@ -742,20 +742,24 @@ struct Flattener {
         return true;
     }
 
-    /* EU_SH_CHAIN_BOX: 2*D half-spaces, leaf k's normal is +-e_(k/2) exactly, its constant finite and non-zero */
-    bool is_axis_box(const std::vector<const Shape *> &chain) const {
-        if (no_box_chains() || (int)chain.size() != 2 * D) return false;
+    /* EU_SH_CHAIN_BOX: 2*D half-spaces, leaf k's normal is +-e_(k/2) exactly, its constant finite (0: not a box, 1: all constants
+     * non-zero, 2: some constant is +-0 -> EU_SH_CHAIN_BOX0) */
+    int is_axis_box(const std::vector<const Shape *> &chain) const {
+        if (no_box_chains() || (int)chain.size() != 2 * D) return 0;
+        bool zero_c = false;
         for (int k = 0; k < 2 * D; k++) {
             const Shape &l = *chain[k];
-            if (l.kind != Shape::HalfSpace) return false;
+            if (l.kind != Shape::HalfSpace) return 0;
             for (int i = 0; i < D; i++) {
-                if (i == k / 2) { if (!(l.a[i] == R(1.0) || l.a[i] == -R(1.0))) return false; }
-                else if (!(l.a[i] == R(0.0))) return false;
+                if (i == k / 2) { if (!(l.a[i] == R(1.0) || l.a[i] == -R(1.0))) return 0; }
+                else if (!(l.a[i] == R(0.0))) return 0;
             }
-            if (!std::isfinite(l.r) || l.r == R(0.0)) return false;
-            if (!(l.signum == R(1.0) || l.signum == -R(1.0))) return false;      /* (the device compares sign bits, chain_matrices_box) */
+            if (!std::isfinite(l.r)) return 0;
+            if (l.r == R(0.0)) zero_c = true;
+            if (!(l.signum == R(1.0) || l.signum == -R(1.0))) return 0;      /* (the device compares sign bits, chain_matrices_box) */
         }
-        return true;
+        /* (zero constants: 3-D only -- the 4-D kernels sit at their register limit and pay for the second variant with spills) */
+        return zero_c ? ((D != 3 || getenv("EU_NO_BOX0_CHAINS")) ? 0 : 2) : 1;
     }
     static bool no_box_chains() { static const bool v = getenv("EU_NO_BOX_CHAINS") != nullptr; return v; }      /* A/B diagnostics */
 
@@ -783,7 +787,7 @@ struct Flattener {
         if (s.kind == Shape::ComposableShape && (s.operation == SetOperation::Union || s.operation == SetOperation::Intersection) &&
             collect_chain(s, s.operation, chain) && chain.size() >= 2 && chain.size() <= EU_CHAIN_MAX) {
             op.kind = (uint8_t)(s.operation == SetOperation::Union ? EU_SH_CHAIN_UNION : EU_SH_CHAIN_INTERSECTION);
-            if (s.operation == SetOperation::Intersection && is_axis_box(chain)) op.kind = EU_SH_CHAIN_BOX;
+            if (s.operation == SetOperation::Intersection) { const int b = is_axis_box(chain); if (b) op.kind = (uint8_t)(b == 2 ? EU_SH_CHAIN_BOX0 : EU_SH_CHAIN_BOX); }
             op.count = (uint8_t)chain.size();
             op.param = (uint32_t)params.size();
             for (auto *leaf : chain) push_halfspace_params(*leaf);
@@ -823,6 +827,7 @@ struct Flattener {
             if (skip_at != (size_t)-1) {
                 if (ops.size() >= 65535) fail(ParserError::CustomError, "too many shape nodes");
                 ops[skip_at].first = (uint16_t)ops.size();        /* index the subtree's root op is about to get */
+                op.count = 1;                                      /* "my first op is my guard" (eval_shape: child a starts behind it) */
             }
             /* a Complement may hand out `a` once more without consuming it (shape.rs:390-392): one element more than it
              * consumed.  At an entity's root only element 0 is ever looked at, so the extra slot is not reserved there. */

@@ -67,7 +67,6 @@ struct EuScene {
     const uint64_t *wrt;    /* the blob in device memory: texel addresses are patched there at upload */
     uint32_t off_ops, off_params, off_entities, n_entities, off_materials, off_transforms, off_code;
     uint32_t off_surfaces, off_color_ops, off_mapped, off_perlin, background, off_bounds;
-    uint32_t has_skip;      /* header flags bit 1: some shape program holds guard ops (EU_SH_SKIP) */
 
     EU_DEV void init(const uint64_t *base) {
         w = base; wrt = base;
@@ -76,7 +75,6 @@ struct EuScene {
         off_materials = h->off_materials; off_transforms = h->off_transforms; off_code = h->off_code;
         off_surfaces = h->off_surfaces; off_color_ops = h->off_color_ops; off_mapped = h->off_mapped;
         off_perlin = h->off_perlin; background = h->background; off_bounds = h->off_bounds;
-        has_skip = h->flags & 2u;
     }
     EU_DEV uint64_t word(uint32_t i) const { return w[i]; }
     EU_DEV eu_f64 dbl(uint32_t i) const { return __longlong_as_double((long long)w[i]); }
@@ -229,10 +227,18 @@ template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const d
 #define EU_HS_STRIDE(D) (2 * (D) + 2)
 
 /* is_point_inside of an EU_SH_CHAIN_BOX (see chain_matrices_box for why one product replaces the dot product) */
-template <int D> EU_DEV bool chain_inside_box(const double *P, const double *p) {
+EU_DEV bool is_neg_zero(double x) { return x == R(0.0) && (eu_hi((eu_f64)x) >> 31) != 0u; }
+template <int D, bool ZC = false> EU_DEV bool chain_inside_box(const double *P, const double *p) {
     bool finite = true;
 #pragma unroll
     for (int m = 0; m < D; m++) finite = finite && __builtin_isfinite(p[m]);
+    if constexpr (ZC) {      /* EU_SH_CHAIN_BOX0: next to a zero constant a product of -0 is the one case the short form gets wrong: the long form then */
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * D; k++) {
+            const double *Pk = P + k * EU_HS_STRIDE(D);
+            if (Pk[D] == R(0.0) && is_neg_zero(Pk[k / 2] * p[k / 2])) finite = false;
+        }
+    }
     bool acc = true;
     if (finite) {
 #pragma unroll
@@ -273,21 +279,23 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, cnt;
         S.op(i, kind, f, param, cnt);
-        if (kind == EU_SH_SKIP) {      /* guard of the bounded subtree ending at op f: a point outside its (enlarged) bounding sphere is in none of its leaves'
-                                        * solids by a margin that dwarfs rounding; the walk stays wave-uniform, so the subtree is skipped only if no lane needs it */
-            if (f <= root) {           /* (a guard whose subtree reaches beyond `root` belongs to an enclosing subtree: not ours) */
-                const double *Bd = S.bounds(param, D);
-                double rr = R(0.0);
+        if (kind >= EU_SH_CHAIN_UNION) {      /* chains and guards (16..): one test keeps them out of the leaves' and composites' way */
+            if (kind == EU_SH_CHAIN_BOX) {
+                st = (st << 1) | (chain_inside_box<D>(S.params(param), p) ? 1ull : 0ull);
+            } else if (D == 3 && kind == EU_SH_CHAIN_BOX0) {      /* (the loader emits it for D = 3 only) */
+                st = (st << 1) | (chain_inside_box<D, true>(S.params(param), p) ? 1ull : 0ull);
+            } else if (kind == EU_SH_SKIP) {  /* guard of the bounded subtree ending at op f: a point outside its (enlarged) bounding sphere is in none of its
+                                               * leaves' solids by a margin that dwarfs rounding; the walk stays wave-uniform: skipped only if no lane needs it */
+                if (f <= root) {              /* (a guard whose subtree reaches beyond `root` belongs to an enclosing subtree: not ours) */
+                    const double *Bd = S.bounds(param, D);
+                    double rr = R(0.0);
 #pragma unroll
-                for (int m = 0; m < D; m++) { const double q = p[m] - Bd[m]; rr = rr + q * q; }
-                if (__ballot(!(rr > Bd[D])) == 0ull) { st <<= 1; i = f; }
+                    for (int m = 0; m < D; m++) { const double q = p[m] - Bd[m]; rr = rr + q * q; }
+                    if (__ballot(!(rr > Bd[D])) == 0ull) { st <<= 1; i = f; }
+                }
+            } else {
+                st = (st << 1) | (chain_inside<D>(kind == EU_SH_CHAIN_UNION, cnt, S.params(param), p) ? 1ull : 0ull);
             }
-            continue;
-        }
-        if (kind == EU_SH_CHAIN_BOX) {
-            st = (st << 1) | (chain_inside_box<D>(S.params(param), p) ? 1ull : 0ull);
-        } else if (kind >= EU_SH_CHAIN_UNION) {
-            st = (st << 1) | (chain_inside<D>(kind == EU_SH_CHAIN_UNION, cnt, S.params(param), p) ? 1ull : 0ull);
         } else if (kind < EU_SH_UNION) {
             st = (st << 1) | (leaf_inside<D>(kind, S.params(param), p) ? 1ull : 0ull);
         } else {
@@ -414,7 +422,13 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
  * non-finite origin or direction (the NaN rays of the general_rotation quirk) or with some d_a == 0 (parallel to a face: the
  * sign of the zero denominator decides between +inf and -inf) is not "regular" and never gets here (ray_is_regular); a
  * non-finite hit point (t overflowed) makes this routine report false.  Either way the ray is traced by the generic routine.
- * 7 (D = 3: 5) flops per dot product become 1. */
+ * 7 (D = 3: 5) flops per dot product become 1.
+ * A ZERO constant (EU_SH_CHAIN_BOX0, ZC = true; e.g. a cuboid with a face in the plane z = 0, as in 3d_room): for x_a != 0 nothing
+ * changes (the sum is s_k x_a, and adding +-0 leaves it).  For x_a == +-0 every term is a zero: the reference's sum is -0 only if ALL
+ * D products are -0, and after adding c_k it is -0 only if moreover c_k is -0; the short form s_k x_a + c_k is -0 iff s_k x_a is -0
+ * and c_k is -0.  With c_k = +0 both are +0; with c_k = -0 they can differ only when the product s_k x_a is -0.  So the routine
+ * reports false (and the wave is traced generically) whenever a product with a zero-constant leaf's normal is -0 -- a coordinate
+ * that is exactly zero with the unlucky sign: it does not happen in practice and costs one comparison per use of such a leaf. */
 template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
     bool ok = true;
 #pragma unroll
@@ -422,7 +436,7 @@ template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
     return ok;
 }
 
-template <int D>
+template <int D, bool ZC = false>
 EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d,
                                double (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
     constexpr uint32_t n = 2 * D;
@@ -434,6 +448,7 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
         if (k < n) {
             const double *Pk = P + k * EU_HS_STRIDE(D);
             const double t = -(Pk[k / 2] * o[k / 2] + Pk[D]) / (Pk[k / 2] * d[k / 2]);
+            if constexpr (ZC) { if (Pk[D] == R(0.0) && is_neg_zero(Pk[k / 2] * o[k / 2])) ok = false; }
             tk[k] = t;
             if (!(t < R(0.0))) pres |= 1u << k;
         }
@@ -451,6 +466,7 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
                 if (j < n && j != i) {
                     const double *Pj = P + j * EU_HS_STRIDE(D);
                     const double r = Pj[j / 2] * loc[j / 2] + Pj[D];
+                    if constexpr (ZC) { if (Pj[D] == R(0.0) && is_neg_zero(Pj[j / 2] * loc[j / 2])) ok = false; }
                     /* signum_j == rust_signum(r) (shape.rs:874-880): signum_j is +-1 (the loader only calls such chains boxes) and r is
                      * finite when loc is (else the result is discarded), so the two are equal exactly when their sign bits are */
                     if (((eu_hi(Pj[D + 1]) ^ eu_hi(r)) >> 31) == 0u) in_k[j] |= 1u << i;
@@ -517,6 +533,8 @@ EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const double *P, const dou
     uint32_t pres = 0, in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];
     if (use_box && kind == EU_SH_CHAIN_BOX) {      /* wave-uniform */
         if (!chain_matrices_box<D>(P, o, d, tk, pres, in_k, lt_k)) fail = true;
+    } else if (D == 3 && use_box && kind == EU_SH_CHAIN_BOX0) {
+        if (!chain_matrices_box<D, true>(P, o, d, tk, pres, in_k, lt_k)) fail = true;
     } else chain_matrices<D>(n, P, o, d, tk, pres, in_k, lt_k);
 #ifdef EU_PROFILE_SHAPE
     if (prof) { __builtin_amdgcn_wave_barrier(); SHP(*prof, 1); }
@@ -658,11 +676,11 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, count;
         S.op(i, kind, f, param, count);
-        if (kind == EU_SH_SKIP) {      /* guard of the bounded subtree ending at op f (flat_scene.h): every ray of the wave misses its sphere -> its stream is empty */
-            if (__ballot(!ray_misses_bound<D>(S.bounds(param, D), o, d)) == 0ull) { lens <<= 8; unk <<= 1; i = f; }
-            continue;
-        }
         if (kind >= EU_SH_CHAIN_UNION) {
+            if (kind == EU_SH_SKIP) {      /* guard of the bounded subtree ending at op f (flat_scene.h): every ray of the wave misses its sphere -> its stream is empty */
+                if (__ballot(!ray_misses_bound<D>(S.bounds(param, D), o, d)) == 0ull) { lens <<= 8; unk <<= 1; i = f; }
+                continue;
+            }
             double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
             const double *Pc = S.params(param);
             const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
@@ -708,12 +726,7 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
         uint32_t kb, fb, pb, cb_;
         S.op(i - 1, kb, fb, pb, cb_);
-        uint32_t fa = f;
-        if (S.has_skip) {   /* this subtree's own guard op, if it has one, sits at f: it is not part of child a */
-            uint32_t k0, f0, p0, c0;
-            S.op(f, k0, f0, p0, c0);
-            if (k0 == EU_SH_SKIP && f0 == i) fa = f + 1;
-        }
+        const uint32_t fa = f + count;      /* a composite op's `count`: 1 if its own guard op sits at f (not part of child a), else 0 */
         const uint32_t ra = fb - 1, rb = i - 1;
         const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
         lens >>= 16;

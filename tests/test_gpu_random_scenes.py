@@ -169,3 +169,50 @@ def test_guarded_subtrees_parity():
         both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
         assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan])
     env.close()
+
+
+@pytest.mark.parametrize("low_precision", [False, True])
+def test_box_with_faces_through_coordinate_planes(low_precision):
+    """A cuboid with faces in the planes x = 0, y = 0, z = 0 (half-space constants +-0: EU_SH_CHAIN_BOX0) as glass, alone and inside a
+    Complement; camera origins with coordinates that are exactly +0 and -0 (the one case where the device's one-product form of the
+    dot product would differ from the reference's sum, so those waves go the generic way).  Must equal the oracle bit for bit."""
+    import json
+    import math
+    from euclider_amd import Parser
+    from oracle.scene_loader import OracleScene, default_texture_loader
+
+    def glass(shape):
+        return {"Entity3Impl::new_with_surface": [shape, {"Vacuum3::new": []}, {"ComposableSurface3": {
+            "reflection_ratio": {"reflection_ratio_fresnel_3": [1.458, 1]},
+            "reflection_direction": {"reflection_direction_specular_3": []},
+            "threshold_direction": {"threshold_direction_snell_3": [1.458]},
+            "surface_color": {"surface_color_uniform_3": [{"Rgba::new": [0.2, 0.4, 0.1, 0.3]}]}}}]}
+
+    box = {"HalfSpace3::cuboid": [{"Point3::new": [2, 2, 2]}, {"Vector3::new": [4, 4, 4]}]}
+    carved = {"ComposableShape3::of": [[{"HalfSpace3::cuboid": [{"Point3::new": [2, -3, -2]}, {"Vector3::new": [4, 2, 4]}]},
+                                        {"Sphere3::new": [{"Point3::new": [2, -3, -2]}, 1.2]}], {"SetOperation": ["Complement"]}]}
+    text = json.dumps({"Universe3": {"camera": {"FreeCamera3": []}, "entities": [glass(box), glass(carved), {"Void3::new_with_vacuum": []}],
+                                     "background": {"MappedTextureImpl3::new": [{"uv_sphere_3": [{"Point3::new": [0, 0, 0]}]},
+                                                                               {"texture_image_nearest_neighbor": ["./resources/simple.png"]}]}}})
+    env = Parser(texture_dirs=[ROOT], low_precision=low_precision).parse(text)
+    osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if low_precision else "")
+    env.camera.max_depth = 6
+    for loc, fwd in (([-3.0, -0.0, 0.0], [1.0, 0.3, 0.2]), ([6.0, 0.0, -0.0], [-1.0, 0.1, 0.0]), ([-0.0, -6.0, -0.0], [0.2, 1.0, 0.3]),
+                     ([2.0, 2.0, -0.0], [0.0, 0.0, 1.0]), ([-0.0, -0.0, -0.0], [1.0, 1.0, 1.0])):
+        n = math.sqrt(sum(x * x for x in fwd))
+        f = [x / n for x in fwd]
+        left = [-f[1], f[0], 0.0] if abs(f[2]) < 0.99 else [0.0, 1.0, 0.0]
+        ln = math.sqrt(sum(x * x for x in left))
+        left = [x / ln for x in left]
+        up = [f[1] * left[2] - f[2] * left[1], f[2] * left[0] - f[0] * left[2], f[0] * left[1] - f[1] * left[0]]
+        ocam = osc.camera()
+        for k in range(3):
+            for cam in (env.camera, ocam):
+                cam.location[k] = loc[k]; cam.forward[k] = f[k]; cam.left[k] = left[k]; cam.up[k] = up[k]
+        img = env.render((128, 72), want_hit_t=True)
+        orgb, ohit, ost = osc.render(128, 72, max_depth=6, want_hit_t=True, camera=ocam)
+        assert np.array_equal(img.data, orgb), (loc, int((img.data != orgb).sum()))
+        assert img.stats == ost
+        both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
+        assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan])
+    env.close()

@@ -110,6 +110,19 @@ def test_bounded_subtrees_get_guard_ops():
     lone.close()
 
 
+def test_box_chain_kinds():
+    """EU_SH_CHAIN_BOX (18) for a cuboid whose half-space constants are all non-zero, EU_SH_CHAIN_BOX0 (19) when a face lies in a
+    coordinate plane (constant +-0), an ordinary Intersection chain (17) when a normal is not +-e_k."""
+    def kinds(shape):
+        env = Parser().parse(universe([entity(shape)]))
+        ops, _ = _flat_ops(env)
+        env.close()
+        return [k for k, _, _ in ops]
+    assert kinds({"HalfSpace3::cuboid": [{"Point3::new": [16, 0, -1]}, {"Vector3::new": [3, 3, 6]}]}) == [18]
+    assert kinds({"HalfSpace3::cuboid": [{"Point3::new": [14, -6, -2]}, {"Vector3::new": [4, 4, 4]}]}) == [19]      # 3d_room's glass block: a face at z = 0
+    assert kinds({"HalfSpace3::cuboid": [{"Point3::new": [2, 2, 2]}, {"Vector3::new": [4, 4, 4]}]}) == [19]
+
+
 @pytest.mark.parametrize("text,kind", [
     ("{ not json", "SyntaxError"),
     (json.dumps({"Universe3": {}, "Universe4": {}}), "InvalidConstructor"),
