@@ -132,9 +132,9 @@ EU_DEV uint32_t wf_append_local(uint32_t *lds_counter, uint32_t n /* 0..2 slots 
  * the generation into LDS; the rays then form one virtual index space that is dealt out grid-stride,
  * and a lane maps its virtual index back to (segment, offset) with a binary search in LDS. */
 #ifndef EU_WF_MAX_SEG
-#define EU_WF_MAX_SEG 1024
+#define EU_WF_MAX_SEG 1024      /* a power of two (wf_map_index halves its step from here); the table is padded with sentinels up to it */
 #endif
-EU_DEV uint32_t wf_build_prefix(const uint32_t *seg_count, uint32_t n_seg, uint32_t *pref /* LDS, n_seg + 1 words */, uint32_t *wave_tot /* LDS, 4 words */) {
+EU_DEV uint32_t wf_build_prefix(const uint32_t *seg_count, uint32_t n_seg, uint32_t *pref /* LDS, EU_WF_MAX_SEG + 1 words */, uint32_t *wave_tot /* LDS, 4 words */) {
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t v[4], s = 0;
 #pragma unroll
