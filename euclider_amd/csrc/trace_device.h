@@ -342,7 +342,8 @@ template <int D> struct FrameStack {
     double data[EU_MAX_DEPTH][2 * D];
 };
 
-#ifdef EU_PROFILE_SHAPE      /* diagnostic build: s_memtime shares of eval_shape's parts -> EuDevCounters::phase[] (tools/shape_profile.py).
+#if defined(EU_PROFILE_SHAPE) || defined(EU_PROFILE_SHADE_WAVE)      /* diagnostic builds: s_memtime shares of eval_shape's parts (EU_PROFILE_SHAPE) or of the shade kernel's
+                              * sections (EU_PROFILE_SHADE_WAVE) -> EuDevCounters::phase[] (tools/shape_profile.py).
                               * The sums live in LDS, one row per wave, and are advanced by the first ACTIVE lane at each stamp: a per-lane copy
                               * would book the time a lane sits masked off to whatever region it wakes up in. */
 struct LaneCounters { uint32_t rays, bg, nan_px, errors; unsigned long long *prof; };      /* prof: [16 sums][last] of this wave */

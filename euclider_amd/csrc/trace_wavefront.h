@@ -52,7 +52,11 @@
 
 /* Diagnostic build only (-DEU_PROFILE_PHASES): s_memtime shares of the shade kernel's sections go to
  * EuDevCounters::phase[]; never to an output.  WF_STAMP(k) closes section k-1 and opens section k. */
-#ifdef EU_PROFILE_PHASES
+#if defined(EU_PROFILE_SHADE_WAVE)      /* wave-level shares of the shade kernel (LDS rows, first active lane: trace_device.h SHP): STAMP(k) closes section k-1
+                                         * (STAMP(0): what lies between two batches -> 15), SUB(k) closes sub-section k; sections do not overlap */
+#define WF_STAMP(k) SHP(cnt, (k) > 0 ? (k) - 1 : 15)
+#define WF_SUB(k) SHP(cnt, (k))
+#elif defined(EU_PROFILE_PHASES)
 #define WF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[(k) - 1] += now_ - last_; last_ = now_; last2_ = now_; } while (0)
 #define WF_SUB(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last2_; last2_ = now_; } while (0)
 #else
@@ -102,7 +106,7 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
         if (v3) atomicAdd(&wg_cnt[3], v3);
     }
     __syncthreads();
-#ifdef EU_PROFILE_SHAPE
+#if defined(EU_PROFILE_SHAPE) || defined(EU_PROFILE_SHADE_WAVE)
     if ((threadIdx.x & 63) == 0 && cnt.prof) for (int q = 0; q < 16; q++) if (cnt.prof[q]) atomicAdd(&counters->phase[q], cnt.prof[q]);
 #endif
     if (threadIdx.x == 0) {
@@ -457,6 +461,13 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     EuScene S;
     S.init(scene_base);
     LaneCounters cnt = {0, 0, 0, 0};
+#ifdef EU_PROFILE_SHADE_WAVE
+    __shared__ unsigned long long prof_rows[EU_WF_BLOCK / 64][17];
+    cnt.prof = prof_rows[threadIdx.x >> 6];
+    if ((threadIdx.x & 63) < 16) cnt.prof[threadIdx.x & 63] = 0;
+    if ((threadIdx.x & 63) == 16) cnt.prof[16] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_wave_barrier();
+#endif
 #ifdef EU_PROFILE_PHASES
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, last2_ = 0;
 #endif

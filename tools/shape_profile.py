@@ -22,5 +22,15 @@ print(scene, w, h, depth, "kernel_ms", env.kernel_ms(), "rays", img.stats["rays"
 names = ["chain: bound test, set-up", "chain: matrices (t_k, IN, LT)", "chain: merge cascade", "chain: push to the hit stack", "leaf ops",
          "composite merges (incl. inside tests)", "entity loop between the ops (entity record, bounding-sphere test, root op, result selection)", "top-level Union chain: first element directly",
          "kernel prologue (scene header, queue prefix)", "per batch: ray out of the prefetch registers, next ray located and requested", "per batch: end of the entity loop, result store", "-"]
+if os.environ.get("EU_PROFILE_KERNEL") == "shade":      # -DEU_PROFILE_SHADE_WAVE build: sections of eu_wf_shade_kernel
+    names = ["(live test)", "ray + hit loaded, hit point, normal, angle (HitCtx)", "surface record, reflection ratio (Fresnel)", "transmission set-up outside the parts below",
+             "reflection direction, node record, delivery of a finished colour", "children that only sample the background", "children appended to the next queue", "-",
+             "surface colour program", "to_pixel of the surface colour", "threshold direction (Snell: rotation)", "child origin, material_at of an exiting ray", "-", "-", "-",
+             "window sort, batch loop, kernel prologue / epilogue"]
+    tot = float(sum(ph[:16])) or 1.0
+    for i in range(16):
+        if ph[i]:
+            print("  %-78s %6.2f%%  %10.1f M" % (names[i], 100.0 * ph[i] / tot, ph[i] / 1e6))
+    sys.exit(0)
 for i in range(11):
     print("  %-78s %6.2f%%  %10.1f M" % (names[i], 100.0 * ph[i] / tot, ph[i] / 1e6))
