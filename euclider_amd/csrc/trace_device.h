@@ -127,7 +127,15 @@ EU_DEV bool is_normal_f64(double x) { uint32_t e = (__float_as_uint(x) >> 23) & 
 EU_DEV bool is_normal_f64(double x) { uint32_t e = (eu_hi(x) >> 20) & 0x7ff; return e != 0 && e != 0x7ff; }
 #endif
 EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
-    double rem = fmod(a, b);
+    /* fmod is exact by definition (a - trunc(a / b) * b, no rounding).  The texture coordinates it is used on lie within two periods:
+     * |a| < b gives a itself; b <= |a| < 2 b gives a -+ b, which is exact as well (Sterbenz: the operands are within a factor of two);
+     * the sign of a zero result does not matter (normalised to +0 below).  Anything else (NaN, b <= 0, further away) takes the library
+     * routine, a software loop of ~80 instructions, four times per texture sample before. */
+    double rem;
+    const double aa = fabs(a);
+    if (aa < b) rem = a;
+    else if (aa < b + b) rem = a < R(0.0) ? a + b : a - b;
+    else rem = fmod(a, b);
     if (rem == R(0.0)) return R(0.0);
     if (a < R(0.0)) return b + rem;
     return rem;
