@@ -14,7 +14,13 @@ workload = sys.argv[3] if len(sys.argv) > 3 else "3d_room.json 1920x1080 depth 8
 pmc_dir = sys.argv[4] if len(sys.argv) > 4 else "pmc"
 round_no = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
+# one file per pass: gpurun MERGES its output into gpurun_out/, so an earlier refresh leaves its files (other run ids) beside the new ones
+latest = {}
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", pmc_dir, "*/*/*counter_collection.csv")):
+    key = os.path.relpath(f, os.path.join(ROOT, "gpurun_out", pmc_dir)).split(os.sep)[0]
+    if key not in latest or os.path.getmtime(f) > os.path.getmtime(latest[key]):
+        latest[key] = f
+for f in sorted(latest.values()):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "eu_" in name:
