@@ -2,7 +2,8 @@
 """bench.py -- Mray/s of the per-pixel trace loop on MI355X (BASELINE.json metric).
 
 One "step" = one Environment::render pass: every pixel of the frame is traced by the HIP
-wavefront pipeline (gen, intersect+shade per generation, resolve, final; scene, textures and the output frame resident in HBM) and the
+wavefront pipeline (intersect + shade per generation, resolve; scene, textures and the output frame resident in HBM; by default with
+kernels specialised for the scene, compiled when the renderer is created) and the
 RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
 
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
@@ -34,7 +35,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks (default: WORLD_SIZE when a launcher started us, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="3d_room.json")
@@ -52,6 +53,11 @@ def parse_args():
                     help="F = f32: the reference's `low_precision` cargo feature (libeuclider_amd_f32.so against libeo_oracle_f32.so). "
                          "A separate mode, never the headline: narrower than the reference's default arithmetic")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short runs of BASELINE configs 3, 4 and the 8K frame")
+    ap.add_argument("--specialize", choices=["sync", "off"], default="sync",
+                    help="sync: trace kernels specialised for the scene, compiled (hiprtc) when the renderer is created, outside the timed "
+                         "region; off: the ahead-of-time kernels that interpret the flat scene")
+    ap.add_argument("--streams", type=int, default=0, help="band pipelines in flight per frame (0 = the library's default)")
+    ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
     return ap.parse_args()
 
 
@@ -143,7 +149,8 @@ def valu_figure(workload_key, kernel_ms):
     """Secondary roofline (the path is f64-VALU bound, not HBM bound): wave-level VALU instructions of one frame
     pipeline (PMC, committed) over the live kernel time, against the VALU issue peak.  The peak is weighted with the kernels'
     instruction mix: cycles per instruction = 4 for the f64 share, 2 for the rest (static mix of each kernel, profiles/
-    r02_isa_mix.json, weighted with each kernel's dynamic VALU count, profiles/r02_room_pmc.json)."""
+    r02_isa_mix.json, weighted with each kernel's dynamic VALU count, profiles/r02_room_pmc.json: a mix measured on 3d_room's
+    round-2 kernels, labelled as such in `mix`)."""
     pmc = load_pmc(workload_key)
     n = pmc.get("valu_wave_insts_per_launch")
     if not n:
@@ -163,7 +170,7 @@ def valu_figure(workload_key, kernel_ms):
                 den += w
         if den:
             cycles = num / den
-            mix_src = "profiles/r02_isa_mix.json x profiles/r02_room_pmc.json"
+            mix_src = "3d_room round-2 kernels: profiles/r02_isa_mix.json x profiles/r02_room_pmc.json"
     except Exception:
         pass
     peak = SIMD_CYCLES_PER_S / cycles / 1e9
@@ -242,14 +249,15 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def other_configs(torch, dev, stream, Parser):
+def other_configs(torch, dev, stream, Parser, args):
     """BASELINE.json configs 3 and 4, the extra 4-D scene and the 8K frame on one GPU: a few steps each, so that the driver's
     record carries them too.  Same timing rule as the headline (device-resident, synchronised on both sides)."""
     out = []
-    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 5, False), ("4d_frame.json", 1920, 1080, 8, 5, False),
-                                          ("4d_cylinders.json", 1920, 1080, 8, 3, False), ("3d_room.json", 7680, 4320, 8, 2, False),
-                                          ("3d_room.json", 1920, 1080, 8, 5, True)):
+    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 12, False), ("4d_frame.json", 1920, 1080, 8, 12, False),
+                                          ("4d_cylinders.json", 1920, 1080, 8, 8, False), ("3d_room.json", 7680, 4320, 8, 3, False),
+                                          ("3d_room.json", 1920, 1080, 10, 12, False), ("3d_room.json", 1920, 1080, 8, 12, True)):
         env = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
+        env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags)
         env.camera.max_depth = depth
         frame = env.frame(W, H, time=0.0, rows=(0, H))
         rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -258,6 +266,7 @@ def other_configs(torch, dev, stream, Parser):
         def step():
             env.render_device(frame, rgba.data_ptr(), None, stream, device=dev.index)
             env.pack_rgb_device(rgba.data_ptr(), rgb.data_ptr(), H * W, stream, device=dev.index)
+        step()
         step()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -276,7 +285,8 @@ def other_configs(torch, dev, stream, Parser):
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
-                                 "flops": flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)}})
+                                 "flops": None if lp else flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)},
+                    "specialized": env.jit_info(device=dev.index)["active"]})
         env.close()
         del rgba, rgb
     return out
@@ -287,6 +297,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus <= 0:      # no --gpus: adapt to the launcher
+        args.gpus = world
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
     if world != args.gpus:
@@ -314,7 +326,11 @@ def main():
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
     env = Parser(low_precision=args.low_precision).parse_file(scene_path)
+    env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags)
     env.camera.max_depth = args.max_depth
+    jit = env.jit_info(device=local_rank)      # (creates the renderer: a specialised one compiles or fetches its kernels here, before any timing)
+    if args.specialize == "sync" and not jit["active"]:
+        raise SystemExit("bench.py: the specialised kernels did not build; run with --specialize off to time the interpreter kernels")
     if args.animate:
         if world != 1:
             raise SystemExit("--animate is a one-GPU mode")
@@ -391,6 +407,7 @@ def main():
         return {"W": W, "H": H, "elapsed": tmax.item(), "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
                 "local_rows": local_rows, "rgb_out": rgb_out, "steps": steps}
 
+    parity_failed = False
     W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
     run = timed_run(W, H, args.steps, args.warmup)
     elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
@@ -423,10 +440,11 @@ def main():
             "config": {"workload": workload + (" low_precision (F = f32: a separate mode, not the headline)" if args.low_precision else ""), "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
+                       "kernels": ("specialised for the scene at renderer creation (hiprtc%s, %.0f ms)" % (", code object from the cache" if jit["from_cache"] else "", jit["compile_ms"])) if jit["active"] else "ahead-of-time, interpreting the flat scene",
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
                        "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(workload), "kernel": "eu_wf_* frame pipeline (gen, %dx intersect+shade, %dx resolve)" % (args.max_depth, args.max_depth), "kernel_ms": kernel_ms,
+                         "traffic": load_traffic(workload), "kernel": "%s frame pipeline (%dx intersect+shade, %dx resolve)" % ("eu_jit_* + eu_wf_resolve" if jit["active"] else "eu_wf_*", args.max_depth, args.max_depth), "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms), "flops": flops_figure(workload, rays_per_step, kernel_ms),
                          "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it"},
         }
@@ -446,11 +464,15 @@ def main():
                              "checked_against": "oracle/ (CPU restatement), same scene, camera, frame"}
         if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json" and not args.low_precision:
             del rgb_out
-            out["other_configs"] = other_configs(torch, dev, stream, Parser)
+            out["other_configs"] = other_configs(torch, dev, stream, Parser, args)
         print(json.dumps(out), flush=True)
+        if out.get("parity", {}).get("mismatch"):
+            parity_failed = True
     env.close()
     if world > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the timed frame differs from the oracle's (see \"parity\" in the line above)")
 
 
 if __name__ == "__main__":

@@ -56,6 +56,21 @@ class SceneInfo(C.Structure):
                 ("flat_bytes", C.c_uint32)]
 
 
+class RendererOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("specialize", C.c_uint32), ("streams", C.c_uint32),
+                ("ray_factor", C.c_double), ("band_pixels", C.c_uint64), ("cache_dir", C.c_char_p), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32), ("jit_flags", C.c_char_p)]
+
+
+class JitInfo(C.Structure):
+    _fields_ = [("requested", C.c_int32), ("active", C.c_int32), ("from_cache", C.c_int32), ("hit_stack_entries", C.c_uint32),
+                ("compile_ms", C.c_double), ("key", C.c_char * 40)]
+
+
+EU_KERNEL_AUTO, EU_KERNEL_WAVEFRONT, EU_KERNEL_STACK = 0, 1, 2
+EU_SPECIALIZE_AUTO, EU_SPECIALIZE_OFF, EU_SPECIALIZE_SYNC = 0, 1, 2
+EU_RENDERER_SHADE_SCENE_GLOBAL = 1
+
 TEXTURE_LOADER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                              C.POINTER(C.c_void_p))
 
@@ -78,7 +93,12 @@ SYMBOLS = {
     "eu_frame_local_rows": (C.c_uint32, [C.POINTER(Frame)]),
     "eu_device_count": (C.c_int, []),
     "eu_renderer_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "eu_renderer_create_opts": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(RendererOpts), C.POINTER(C.c_void_p), C.c_char_p,
+                                          C.c_size_t]),
     "eu_renderer_destroy": (None, [C.c_void_p]),
+    "eu_renderer_jit_info": (C.c_int, [C.c_void_p, C.POINTER(JitInfo)]),
+    "eu_scene_jit_source": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]),
+    "eu_scene_jit_precompile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(JitInfo), C.c_char_p, C.c_size_t]),
     "eu_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "eu_pack_rgb_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -98,6 +118,8 @@ SYMBOLS = {
     "eu_sequence_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(Stats)]),
     "eu_multi_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "eu_multi_create_opts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(RendererOpts), C.POINTER(C.c_void_p),
+                                       C.c_char_p, C.c_size_t]),
     "eu_multi_destroy": (None, [C.c_void_p]),
     "eu_render_multi": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_void_p),
                                   C.POINTER(Stats)]),

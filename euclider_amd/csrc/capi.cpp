@@ -9,6 +9,7 @@
 
 #include "../../include/euclider_amd.h"
 #include "scene_host.hpp"
+#include "jit.hpp"
 
 using namespace euclider;
 
@@ -62,3 +63,30 @@ extern "C" const void *eu_scene_flat(const eu_scene *s, size_t *bytes) {
     if (bytes) *bytes = s->flat.words.size() * 8;
     return s->flat.words.data();
 }
+
+/* ---- scene-specialised kernels (jit.hpp): source and ahead-of-time compilation, no GPU involved ---- */
+extern "C" int eu_scene_jit_source(const eu_scene *scene, char **source, char *key) {
+    if (!scene || !source) return EU_ERR_INVALID_ARGUMENT;
+    const euclider::JitPlan plan = euclider::jit_generate(scene->flat);
+    char *buf = (char *)eu_alloc(plan.source.size() + 1);
+    if (!buf) return EU_ERR_INVALID_ARGUMENT;
+    memcpy(buf, plan.source.c_str(), plan.source.size() + 1);
+    *source = buf;
+    if (key) snprintf(key, 40, "%s", plan.key.c_str());
+    return EU_OK;
+}
+
+extern "C" int eu_scene_jit_precompile(const eu_scene *scene, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen) {
+    if (!scene) return EU_ERR_INVALID_ARGUMENT;
+    const euclider::JitPlan plan = euclider::jit_generate(scene->flat);
+    euclider::JitBuild b;
+    const int rc = euclider::jit_build(plan, cache_dir ? cache_dir : "", b);
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->requested = 1; info->from_cache = b.from_cache ? 1 : 0; info->hit_stack_entries = plan.hs_cap; info->compile_ms = b.compile_ms;
+        snprintf(info->key, sizeof info->key, "%s", plan.key.c_str());
+    }
+    if (rc != EU_OK) set_err(err, errlen, b.log);
+    return rc;
+}
+

@@ -19,11 +19,14 @@
 #ifndef EU_MATH_H
 #define EU_MATH_H
 
+#if defined(__cplusplus)
+#include "eu_platform.h"
+#else
 #include <stdint.h>
 #include <math.h>
+#endif
 
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define EU_HD __host__ __device__ __attribute__((always_inline))
 #else
 #define EU_HD

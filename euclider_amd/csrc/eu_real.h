@@ -3,37 +3,37 @@
  *
  * The reference is generic over `F`: f64 by default, f32 with the cargo feature `low_precision`
  * (/root/reference/Cargo.toml:18-20, src/main.rs:46-49).  A cargo feature makes a different binary; so does this: the same
- * sources built with -DEU_LOW_PRECISION give libeuclider_amd_f32.so, in which every `double` of
- * the trace path -- rays, hits, colours, scene parameters, the loader's constructor arithmetic -- is a float.  That is done the
- * blunt way, by redefining the keyword AFTER the system headers and the public C ABI have been seen, plus:
+ * sources built with -DEU_LOW_PRECISION give libeuclider_amd_f32.so, in which `real` -- the type of rays, hits, colours, scene
+ * parameters and the loader's constructor arithmetic -- is float.  Conventions:
  *   - R(x) around every floating literal of the path, so that expressions are evaluated in F like the reference's
  *     `<F as NumCast>::from(x)` constants, not in double with a final rounding;
- *   - eu_f64 wherever a value stays 64-bit whatever F is: the public ABI (camera pose, hit distances, trace_screen_point's
- *     colour), the elementary functions' internals (eu_math.h), and the LinearSpace expressions (meval evaluates in f64 and the
- *     result is cast to F: material.rs:99-111).
- * In the default build R(x) is x and nothing changes (checked: identical frames before and after this header was introduced).
+ *   - eu_f64 (= double) wherever a value stays 64-bit whatever F is: the public ABI (camera pose, hit distances,
+ *     trace_screen_point's colour), the elementary functions' internals (eu_math.h), and the LinearSpace expressions (meval
+ *     evaluates in f64 and the result is cast to F: material.rs:99-111).
+ * (Rounds 1-2 redefined the keyword `double` instead; round 3 replaced that by this typedef, frames unchanged.)
  */
 #ifndef EU_REAL_H
 #define EU_REAL_H
 
 typedef double eu_f64;
-#define R(x) ((double)(x))
 
 #ifdef EU_LOW_PRECISION
 #define EU_REAL_BITS 32
-#define double float
+typedef float real;
 #else
 #define EU_REAL_BITS 64
+typedef double real;
 #endif
+#define R(x) ((real)(x))
 
 /* the elementary functions are evaluated in f64 (eu_math.h) and rounded to F at once, so that no expression continues in double
  * behind a call (in the default build the casts are no-ops); eu_*_f64 are the untouched entry points */
-#define eu_acos(x) ((double)eu_acos(x))
-#define eu_asin(x) ((double)eu_asin(x))
-#define eu_sin(x) ((double)eu_sin(x))
-#define eu_cos(x) ((double)eu_cos(x))
-#define eu_tan(x) ((double)eu_tan(x))
-#define eu_atan(x) ((double)eu_atan(x))
-#define eu_atan2(y, x) ((double)eu_atan2(y, x))
+#define eu_acos(x) ((real)eu_acos(x))
+#define eu_asin(x) ((real)eu_asin(x))
+#define eu_sin(x) ((real)eu_sin(x))
+#define eu_cos(x) ((real)eu_cos(x))
+#define eu_tan(x) ((real)eu_tan(x))
+#define eu_atan(x) ((real)eu_atan(x))
+#define eu_atan2(y, x) ((real)eu_atan2(y, x))
 
 #endif

@@ -21,7 +21,7 @@
 #ifndef EU_FLAT_SCENE_H
 #define EU_FLAT_SCENE_H
 
-#include <stdint.h>
+#include "eu_platform.h"
 
 #define EU_FLAT_MAGIC 0x45554346u /* "EUCF" */
 #define EU_FLAT_VERSION 1u

@@ -1,0 +1,661 @@
+/*
+ * jit.cpp -- generator of the scene-specialised trace kernels + hiprtc build + code-object cache (see jit.hpp).
+ * Host code only; nothing here traces rays.  The generator reads the SAME flat scene the interpreter kernels read
+ * (flat_scene.h), so what it emits is by construction the program the interpreter would have walked.
+ */
+#include "jit.hpp"
+
+#include <hip/hiprtc.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace euclider {
+
+#define EU_JIT_VERSION "eu-jit-3"
+
+/* the device headers, embedded at build time (csrc/Makefile: jit_headers.inc) */
+struct EmbeddedHeader { const char *name; const char *text; };
+static const EmbeddedHeader kHeaders[] = {
+#include "jit_headers.inc"
+};
+static constexpr int kNumHeaders = (int)(sizeof(kHeaders) / sizeof(kHeaders[0]));
+
+static const char *const kCompileFlags[] = {
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-c++11-narrowing",
+    /* MachineLICM hoists constant materialisation and invariant scalar loads out of the ray loops and lets them live (and spill) across
+     * the whole kernel: 3d_room shade 159 -> 0 SGPR spills, 154 -> 125 VGPRs without it */
+    "-mllvm", "-disable-machine-licm",
+#ifdef EU_LOW_PRECISION
+    "-DEU_LOW_PRECISION",
+#endif
+};
+
+namespace {
+
+struct Out {
+    std::string s;
+    void f(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        int n = vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        if (n < 0) return;
+        if ((size_t)n < sizeof buf) { s.append(buf, (size_t)n); return; }
+        std::string big((size_t)n + 1, '\0');
+        va_start(ap, fmt);
+        vsnprintf(&big[0], big.size(), fmt, ap);
+        va_end(ap);
+        s.append(big.c_str(), (size_t)n);
+    }
+};
+
+/* exact literals: hexadecimal floating point for finite values, bit patterns for the rest */
+static std::string lit64(eu_f64 v) {
+    char b[64];
+    if (std::isfinite(v)) snprintf(b, sizeof b, "%a", v);
+    else { uint64_t u; memcpy(&u, &v, 8); snprintf(b, sizeof b, "__builtin_bit_cast(double, 0x%016llxull)", (unsigned long long)u); }
+    return b;
+}
+static std::string litr(real v) {
+#if EU_REAL_BITS == 32
+    char b[64];
+    if (std::isfinite(v)) snprintf(b, sizeof b, "%af", (double)v);
+    else { uint32_t u; memcpy(&u, &v, 4); snprintf(b, sizeof b, "__builtin_bit_cast(float, 0x%08xu)", u); }
+    return b;
+#else
+    return lit64(v);
+#endif
+}
+
+struct OpView { uint32_t kind, count, first, param; };
+struct EntityView { uint32_t shape_first, shape_root, material; int32_t surface; uint32_t max_hits, bound; };
+
+struct Gen {
+    const uint64_t *w;
+    const EuFlatHeader *h;
+    int D;
+    Out o;
+    std::set<std::pair<uint32_t, uint32_t>> inside_done;
+    std::string inside_defs;      /* static member functions in_<first>_<root>(p) */
+
+    explicit Gen(const FlatScene &flat) : w(flat.words.data()), h(&flat.header()), D((int)flat.header().dim) {}
+
+    OpView op(uint32_t i) const {
+        const uint64_t x = w[h->off_ops + i];
+        return OpView{(uint32_t)(x & 0xff), (uint32_t)((x >> 8) & 0xff), (uint32_t)((x >> 16) & 0xffff), (uint32_t)(x >> 32)};
+    }
+    EntityView entity(uint32_t e) const {
+        const uint64_t a = w[h->off_entities + 2 * e], b = w[h->off_entities + 2 * e + 1];
+        return EntityView{(uint32_t)(a & 0xffffu), (uint32_t)((a >> 16) & 0xffffu), (uint32_t)((a >> 32) & 0xffffu), (int32_t)(int16_t)(uint16_t)(a >> 48),
+                          (uint32_t)b, (uint32_t)(b >> 32)};
+    }
+    const real *params(uint32_t off) const { return (const real *)(w + h->off_params) + off; }
+    const real *bounds(uint32_t b) const { return (const real *)(w + h->off_bounds) + (uint32_t)(D + 2) * b; }
+    const EuFlatSurface *surface(uint32_t s) const { return (const EuFlatSurface *)(w + h->off_surfaces + 8 * s); }
+    const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + h->off_color_ops + 16 * c); }
+    const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + h->off_mapped + 8 * m); }
+
+    static const char *kind_name(uint32_t k) {
+        switch (k) {
+        case EU_SH_VOID: return "EU_SH_VOID"; case EU_SH_SPHERE: return "EU_SH_SPHERE"; case EU_SH_PLANE: return "EU_SH_PLANE";
+        case EU_SH_HALFSPACE: return "EU_SH_HALFSPACE"; case EU_SH_CYLINDER: return "EU_SH_CYLINDER";
+        case EU_SH_UNION: return "EU_SH_UNION"; case EU_SH_INTERSECTION: return "EU_SH_INTERSECTION";
+        case EU_SH_COMPLEMENT: return "EU_SH_COMPLEMENT"; case EU_SH_SYMDIFF: return "EU_SH_SYMDIFF";
+        case EU_SH_CHAIN_UNION: return "EU_SH_CHAIN_UNION"; case EU_SH_CHAIN_INTERSECTION: return "EU_SH_CHAIN_INTERSECTION";
+        case EU_SH_CHAIN_BOX: return "EU_SH_CHAIN_BOX"; case EU_SH_CHAIN_BOX0: return "EU_SH_CHAIN_BOX0";
+        default: return "EU_SH_VOID";
+        }
+    }
+    uint32_t param_count(const OpView &p) const {      /* reals behind op.param */
+        const uint32_t d = (uint32_t)D;
+        switch (p.kind) {
+        case EU_SH_SPHERE: return d + 2;
+        case EU_SH_PLANE: return d + 1;
+        case EU_SH_HALFSPACE: return 2 * d + 2;
+        case EU_SH_CYLINDER: return 2 * d + 2;
+        case EU_SH_CHAIN_UNION: case EU_SH_CHAIN_INTERSECTION: case EU_SH_CHAIN_BOX: case EU_SH_CHAIN_BOX0:
+            return p.count * (2 * d + 2) + d + 2;      /* the leaves, then the chain's bounding sphere */
+        default: return 0;
+        }
+    }
+    /* `static constexpr real NAME[] = {...};` */
+    std::string real_array(const std::string &name, const real *v, uint32_t n) const {
+        std::string s = "static constexpr real " + name + "[] = {";
+        if (n == 0) s += "R(0.0)";
+        for (uint32_t k = 0; k < n; k++) { if (k) s += ", "; s += litr(v[k]); }
+        s += "};";
+        return s;
+    }
+    /* Shape parameters and bounding spheres are NOT emitted as constants: they are read from the resident scene at constant offsets
+     * (wave-uniform addresses: scalar loads with immediate offsets).  As literals every double costs two s_mov_b32 and the optimiser,
+     * seeing through them, reshapes the chain matrices into hundreds of simultaneously live lane masks (measured: 166 VGPRs + 115
+     * spilled, 533 SGPR spills for 3d_room's intersect kernel against 105 / 47 with the parameters in memory). */
+    bool shape_params_in_memory = true;
+    std::string op_params(const std::string &name, uint32_t i) const {
+        const OpView p = op(i);
+        if (!shape_params_in_memory) return real_array(name, params(p.param), param_count(p));
+        char b[160];
+        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + %uu;", name.c_str(), h->off_params, p.param);
+        return b;
+    }
+    std::string bound_array(const std::string &name, uint32_t bi) const {
+        if (!shape_params_in_memory) return real_array(name, bounds(bi), (uint32_t)D + 2);
+        char b[160];
+        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + %uu;", name.c_str(), h->off_bounds, (uint32_t)(D + 2) * bi);
+        return b;
+    }
+
+    /* ---- is_point_inside of the subtree ops[first..root] (shape.rs:589-600) as an expression; see inside_subtree() ---- */
+    std::string inside_fn(uint32_t first, uint32_t root) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "in_%u_%u", first, root);
+        if (inside_done.insert({first, root}).second) {
+            Out d;
+            d.f("    static EU_DEV bool %s(const EuScene &S, const real *p) {\n", nm);
+            std::vector<std::string> st;
+            emit_inside_range(d, first, root, root, st);
+            d.f("        return %s;\n    }\n", st.empty() ? "false" : st.back().c_str());
+            inside_defs += d.s;
+        }
+        return nm;
+    }
+    /* walks ops[first..last] (a prefix of the subtree ending at `root`), leaves one bool variable name per finished subtree on `st` */
+    void emit_inside_range(Out &d, uint32_t first, uint32_t last, uint32_t root, std::vector<std::string> &st) {
+        for (uint32_t i = first; i <= last; i++) {
+            const OpView p = op(i);
+            char v[32];
+            snprintf(v, sizeof v, "b%u", i);
+            if (p.kind == EU_SH_SKIP) {
+                /* guard of the bounded subtree ending at op p.first: a point outside its (enlarged) bounding sphere is in none of its
+                 * leaves' solids by a margin that dwarfs rounding (trace_device.h inside_subtree: there the test is wave-uniform; per
+                 * lane it gives the same answer by the same argument) */
+                if (p.first > root) continue;      /* belongs to an enclosing subtree: not ours */
+                std::vector<std::string> sub;
+                snprintf(v, sizeof v, "bg%u", p.first);
+                d.f("        bool %s = false;\n        { %s\n          if (!point_outside_bound<%d>(G, p)) {\n", v, bound_array("G", p.param).c_str(), D);
+                emit_inside_range(d, i + 1, p.first, p.first, sub);
+                d.f("          %s = %s;\n        } }\n", v, sub.empty() ? "false" : sub.back().c_str());
+                st.push_back(v);
+                i = p.first;
+                continue;
+            }
+            if (p.kind >= EU_SH_CHAIN_UNION) {
+                const char *call = p.kind == EU_SH_CHAIN_BOX ? "chain_inside_box<%d>(P, p)" : (p.kind == EU_SH_CHAIN_BOX0 && D == 3) ? "chain_inside_box<%d, true>(P, p)" : nullptr;
+                d.f("        bool %s; { %s ", v, op_params("P", i).c_str());
+                if (call) { d.f("%s = ", v); d.f(call, D); d.f("; }\n"); }
+                else d.f("%s = chain_inside<%d>(%s, %uu, P, p); }\n", v, D, p.kind == EU_SH_CHAIN_UNION ? "true" : "false", p.count);
+                st.push_back(v);
+            } else if (p.kind < EU_SH_UNION) {
+                d.f("        bool %s; { %s %s = leaf_inside<%d>(%s, P, p); }\n", v, op_params("P", i).c_str(), v, D, kind_name(p.kind));
+                st.push_back(v);
+            } else {
+                if (st.size() < 2) { d.f("        /* malformed program at op %u */\n", i); continue; }
+                const std::string b = st.back(); st.pop_back();
+                const std::string a = st.back(); st.pop_back();
+                const char *expr = p.kind == EU_SH_UNION ? "(%s | %s)" : p.kind == EU_SH_INTERSECTION ? "(%s & %s)" : p.kind == EU_SH_COMPLEMENT ? "(%s & !%s)" : "(%s ^ %s)";
+                d.f("        const bool %s = ", v); d.f(expr, a.c_str(), b.c_str()); d.f(";\n");
+                st.push_back(v);
+            }
+        }
+    }
+
+    /* ---- eval_shape of ops[first..last] inside a tree, straight line; `st`: names of the CsgList variables on the hit stack ---- */
+    void emit_tree_range(Out &d, uint32_t first, uint32_t last, uint32_t root, std::vector<std::string> &st, const std::string &ind) {
+        for (uint32_t i = first; i <= last; i++) {
+            const OpView p = op(i);
+            char v[32];
+            snprintf(v, sizeof v, "L%u", i);
+            if (p.kind == EU_SH_SKIP) {      /* every ray of the wave misses the subtree's sphere -> its stream is empty (eval_shape) */
+                snprintf(v, sizeof v, "LG%u", p.first);
+                d.f("%sCsgList %s = {0u, false, false};\n%s{ %s\n%s  if (__ballot(!ray_misses_bound<%d>(G, o, d)) != 0ull) {\n", ind.c_str(), v, ind.c_str(),
+                    bound_array("G", p.param).c_str(), ind.c_str(), D);
+                std::vector<std::string> sub;
+                emit_tree_range(d, i + 1, p.first, root, sub, ind + "    ");
+                d.f("%s    %s = %s;\n%s} }\n", ind.c_str(), v, sub.empty() ? "CsgList{0u, false, false}" : sub.back().c_str(), ind.c_str());
+                st.push_back(v);
+                i = p.first;
+                continue;
+            }
+            if (p.kind >= EU_SH_CHAIN_UNION) {
+                d.f("%sCsgList %s; { %s %s = push_chain<%d>(%s, %uu, P, o, d, hs, sp, %uu, cnt, use_box, fail); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D,
+                    kind_name(p.kind), p.count, i);
+                st.push_back(v);
+            } else if (p.kind < EU_SH_UNION) {
+                d.f("%sCsgList %s; { %s %s = push_leaf<%d>(%s, P, o, d, hs, sp, %uu, cnt); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D, kind_name(p.kind), i);
+                st.push_back(v);
+            } else {
+                if (st.size() < 2) { d.f("%s/* malformed program at op %u */\n", ind.c_str(), i); continue; }
+                const OpView pb = op(i - 1);
+                const uint32_t fb = pb.first, fa = p.first + p.count, ra = fb - 1, rb = i - 1;
+                const std::string b = st.back(); st.pop_back();
+                const std::string a = st.back(); st.pop_back();
+                const std::string ia = inside_fn(fa, ra), ib = inside_fn(fb, rb);
+                d.f("%sconst CsgList %s = csg_merge<%d>(%s, %s, hs, sp, %s, %s, o, d, cnt, [&S](const real *q) { return %s(S, q); }, [&S](const real *q) { return %s(S, q); });\n",
+                    ind.c_str(), v, D, kind_name(p.kind), i == root ? "true" : "false", a.c_str(), b.c_str(), ia.c_str(), ib.c_str());
+                st.push_back(v);
+            }
+        }
+    }
+
+    /* ---- LinearSpace expressions (material.rs:59-163): one RPN program as straight-line f64 statements; returns the result's name ---- */
+    std::string emit_rpn(Out &d, uint64_t prog, const std::string &pre, const std::string &ind) {
+        const uint32_t off = (uint32_t)prog, len = (uint32_t)(prog >> 32);
+        std::vector<std::string> st;
+        int tmp = 0;
+        auto fresh = [&]() { char b[48]; snprintf(b, sizeof b, "%s_%d", pre.c_str(), tmp++); return std::string(b); };
+        auto top = [&](size_t back) -> std::string { return st.size() > back ? st[st.size() - 1 - back] : std::string("0.0"); };
+        for (uint32_t i = 0; i < len; i++) {
+            const uint64_t wd = w[h->off_code + off + i];
+            const uint32_t opc = (uint32_t)wd, arg = (uint32_t)(wd >> 32);
+            switch (opc) {
+            case EU_RPN_CONST: {
+                i++;
+                eu_f64 c; memcpy(&c, &w[h->off_code + off + i], 8);
+                const std::string v = fresh();
+                d.f("%sconst eu_f64 %s = %s;\n", ind.c_str(), v.c_str(), lit64(c).c_str());
+                st.push_back(v);
+                break;
+            }
+            case EU_RPN_VAR: {
+                const std::string v = fresh();
+                d.f("%sconst eu_f64 %s = ctx[%u];\n", ind.c_str(), v.c_str(), (arg >= 1 && (int)arg < D) ? arg : 0u);
+                st.push_back(v);
+                break;
+            }
+            case EU_RPN_NEG: {
+                const std::string v = fresh();
+                d.f("%sconst eu_f64 %s = -%s;\n", ind.c_str(), v.c_str(), top(0).c_str());
+                if (!st.empty()) st.pop_back();
+                st.push_back(v);
+                break;
+            }
+            case EU_RPN_FN: {
+                const bool binary = arg == EU_FN_MIN || arg == EU_FN_MAX || arg == EU_FN_ATAN2;
+                const std::string y = top(0);
+                if (!st.empty()) st.pop_back();
+                std::string x = y;
+                if (binary) { x = top(0); if (!st.empty()) st.pop_back(); }
+                const std::string v = fresh();
+                const char *fn1 = nullptr, *fn2 = nullptr;
+                switch (arg) {
+                case EU_FN_SQRT: fn1 = "sqrt"; break; case EU_FN_ABS: fn1 = "fabs"; break; case EU_FN_FLOOR: fn1 = "floor"; break;
+                case EU_FN_CEIL: fn1 = "ceil"; break; case EU_FN_MIN: fn2 = "rpn_min"; break; case EU_FN_MAX: fn2 = "rpn_max"; break;
+                case EU_FN_SIN: fn1 = "eu_sin_f64"; break; case EU_FN_COS: fn1 = "eu_cos_f64"; break; case EU_FN_TAN: fn1 = "eu_tan_f64"; break;
+                case EU_FN_ASIN: fn1 = "eu_asin_f64"; break; case EU_FN_ACOS: fn1 = "eu_acos_f64"; break; case EU_FN_ATAN: fn1 = "eu_atan_f64"; break;
+                case EU_FN_ATAN2: fn2 = "eu_atan2_f64"; break; default: fn1 = "rpn_signum"; break;
+                }
+                if (fn2) d.f("%sconst eu_f64 %s = %s(%s, %s);\n", ind.c_str(), v.c_str(), fn2, x.c_str(), y.c_str());
+                else d.f("%sconst eu_f64 %s = %s((eu_f64)%s);\n", ind.c_str(), v.c_str(), fn1, x.c_str());
+                st.push_back(v);
+                break;
+            }
+            default: {
+                const std::string y = top(0);
+                if (!st.empty()) st.pop_back();
+                const std::string x = top(0);
+                if (!st.empty()) st.pop_back();
+                const std::string v = fresh();
+                switch (opc) {
+                case EU_RPN_ADD: d.f("%sconst eu_f64 %s = %s + %s;\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                case EU_RPN_SUB: d.f("%sconst eu_f64 %s = %s - %s;\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                case EU_RPN_MUL: d.f("%sconst eu_f64 %s = %s * %s;\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                case EU_RPN_DIV: d.f("%sconst eu_f64 %s = %s / %s;\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                case EU_RPN_REM: d.f("%sconst eu_f64 %s = fmod((eu_f64)%s, (eu_f64)%s);\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                default: d.f("%sconst eu_f64 %s = pow_int(%s, %s);\n", ind.c_str(), v.c_str(), x.c_str(), y.c_str()); break;
+                }
+                st.push_back(v);
+                break;
+            }
+            }
+        }
+        return st.empty() ? std::string("0.0") : st.front();      /* eval_rpn returns the BOTTOM of its stack */
+    }
+
+    /* Material::enter (exit_ = false) / exit of material m (material.rs:135-162) on `dir` */
+    void emit_material(Out &d, uint32_t m, bool exit_, const std::string &ind) {
+        const uint64_t mw = w[h->off_materials + m];
+        const uint32_t kind = (uint32_t)mw & 0xff, ntr = ((uint32_t)mw >> 8), first = (uint32_t)(mw >> 32);
+        if (kind != EU_MAT_LINEAR) return;
+        for (uint32_t k = 0; k < ntr; k++) {
+            const uint32_t tr = exit_ ? (first + ntr - 1 - k) : (first + k);
+            d.f("%s{ eu_f64 ctx[%d];\n", ind.c_str(), D);      /* the evaluation context is the vector BEFORE the transformation (material.rs:99-111) */
+            for (int i = 0; i < D; i++) d.f("%s  ctx[%d] = dir[%d];\n", ind.c_str(), i, i);
+            for (int i = 0; i < D; i++) {
+                char pre[32];
+                snprintf(pre, sizeof pre, "t%u_%d", tr, i);
+                const std::string r = emit_rpn(d, w[h->off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i], pre, ind + "  ");
+                d.f("%s  dir[%d] = (real)%s;\n", ind.c_str(), i, r.c_str());
+            }
+            d.f("%s}\n", ind.c_str());
+        }
+    }
+
+    std::string mapped_record(const std::string &name, uint32_t id) const {
+        const EuFlatMapped *M = mapped(id);
+        Out d;
+        d.f("static constexpr EuFlatMapped %s = {%uu, %uu, %uu, %uu, 0ull, {%s, %s, %s}, %s, %s};", name.c_str(), M->tex_kind, M->uv_kind, M->w, M->h,
+            lit64(M->center[0]).c_str(), lit64(M->center[1]).c_str(), lit64(M->center[2]).c_str(), lit64(M->wd).c_str(), lit64(M->hd).c_str());
+        return d.s;
+    }
+
+    void generate() {
+        const uint32_t ne = h->n_entities;
+        o.f("/* generated by euclider_amd (%s): trace kernels specialised for one scene: %u entities, %u shape ops, dim %d */\n", EU_JIT_VERSION, ne, h->n_ops, D);
+        o.f("#include \"trace_wavefront.h\"\n\n");
+        o.f("template <int D> EU_DEV bool point_outside_bound(const real *Bd, const real *p) {\n    real rr = R(0.0);\n#pragma unroll\n"
+            "    for (int m = 0; m < D; m++) { const real q = p[m] - Bd[m]; rr = rr + q * q; }\n    return rr > Bd[D];\n}\n\n");
+
+        /* ---- trace_closest ---- */
+        Out tc;
+        tc.f("    /* trace_closest (universe/mod.rs:85-147): every surfaced entity's shape program as a straight line */\n");
+        tc.f("    template <class HS>\n    static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, bool use_box, bool &fail,\n"
+             "                                     bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {\n");
+        for (uint32_t e = 0; e < ne; e++) {
+            const EntityView E = entity(e);
+            if (E.surface < 0) continue;
+            tc.f("        {   /* entity %u: ops %u..%u */\n", e, E.shape_first, E.shape_root);
+            std::string ind = "            ";
+            if (E.bound != 0xffffffffu) { tc.f("            %s\n            if (!ray_misses_bound<%d>(B, o, d)) {\n", bound_array("B", E.bound).c_str(), D); ind += "    "; }
+            tc.f("%sreal t = R(0.0); uint32_t code = 0, n;\n", ind.c_str());
+            if (E.shape_first == E.shape_root) {
+                const OpView p = op(E.shape_root);
+                tc.f("%s{ %s n = eval_single<%d>(%s, %uu, P, o, d, hs, %uu, cnt, t, code, use_box, fail); }\n", ind.c_str(), op_params("P", E.shape_root).c_str(), D,
+                     kind_name(p.kind), p.count, E.shape_root);
+            } else {
+                tc.f("%s{ uint32_t sp = 0;\n", ind.c_str());
+                std::vector<std::string> st;
+                emit_tree_range(tc, E.shape_first, E.shape_root, E.shape_root, st, ind + "  ");
+                tc.f("%s  n = csg_root_result(%s, hs, cnt, t, code); }\n", ind.c_str(), st.empty() ? "CsgList{0u, false, false}" : st.back().c_str());
+            }
+            tc.f("%sif (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = %uu; }\n", ind.c_str(), e);
+            if (E.bound != 0xffffffffu) tc.f("            }\n");
+            tc.f("        }\n");
+        }
+        tc.f("    }\n");
+
+        /* ---- hit_normal ---- */
+        Out hn;
+        hn.f("    static EU_DEV void hit_normal(const EuScene &S, uint32_t ent, uint32_t code, const real *o, const real *d, const real *loc, real *n) {\n"
+             "        switch (code & 0xffffu) {\n");
+        for (uint32_t e = 0; e < ne; e++) {
+            const EntityView E = entity(e);
+            if (E.surface < 0) continue;
+            for (uint32_t i = E.shape_first; i <= E.shape_root; i++) {
+                const OpView p = op(i);
+                if (p.kind == EU_SH_SKIP || (p.kind >= EU_SH_UNION && p.kind < EU_SH_CHAIN_UNION) || p.kind == EU_SH_VOID) continue;
+                if (p.kind >= EU_SH_CHAIN_UNION) {      /* a chain's leaf counts as a half-space: its normal is the stored n * -signum (shape.rs:860) */
+                    const real *P = params(p.param);
+                    hn.f("        case %uu: { static constexpr real NF[%u][%d] = {", i, p.count, D);
+                    for (uint32_t k = 0; k < p.count; k++) {
+                        hn.f("%s{", k ? ", " : "");
+                        for (int m = 0; m < D; m++) hn.f("%s%s", m ? ", " : "", litr(P[k * (2 * (uint32_t)D + 2) + (uint32_t)D + 2 + (uint32_t)m]).c_str());
+                        hn.f("}");
+                    }
+                    hn.f("};\n            const uint32_t k = (code >> 16) & 0xffu;\n");
+                    for (int m = 0; m < D; m++) hn.f("            n[%d] = NF[k][%d];\n", m, m);
+                    hn.f("            break; }\n");
+                } else {
+                    hn.f("        case %uu: { %s leaf_normal<%d>(%s, P, o, d, loc, n); break; }\n", i, op_params("P", i).c_str(), D, kind_name(p.kind));
+                }
+            }
+        }
+        hn.f("        default: break;\n        }\n        if (code & EU_HIT_FLIP) {\n");
+        for (int m = 0; m < D; m++) hn.f("            n[%d] = -n[%d];\n", m, m);
+        hn.f("        }\n    }\n");
+
+        /* ---- surfaces ---- */
+        Out sf;
+        std::map<int32_t, std::vector<uint32_t>> by_surface;
+        for (uint32_t e = 0; e < ne; e++) { const EntityView E = entity(e); if (E.surface >= 0) by_surface[E.surface].push_back(e); }
+        for (auto &kv : by_surface) {
+            const EuFlatSurface *F = surface((uint32_t)kv.first);
+            sf.f("    static EU_DEV void surf_%d(const EuScene &S, HitCtx<%d> &c, real time_s, LaneCounters &cnt, SurfaceEval<%d> &E) {\n", kv.first, D, D);
+            sf.f("        static constexpr EuFlatSurface F = {%uu, %uu, %uu, %uu, %s, %s, %s, %s, {0.0, 0.0}};\n", F->ratio_kind, F->thr_kind, F->color_first, F->color_root,
+                 lit64(F->ratio_p0).c_str(), lit64(F->ratio_p1).c_str(), lit64(F->thr_p0).c_str(), lit64(F->thr_p0_inv).c_str());
+            sf.f("        surface_eval<%d>(&F, c, cnt, E, [&]() -> Rgba {\n", D);
+            std::vector<std::string> st;
+            for (uint32_t i = F->color_first; i <= F->color_root; i++) {
+                const EuFlatColorOp *C = color_op(i);
+                char v[32], cn[32];
+                snprintf(v, sizeof v, "v%u", i);
+                snprintf(cn, sizeof cn, "C%u", i);
+                sf.f("            static constexpr EuFlatColorOp %s = {%uu, %uu, %uu, 0u, {%s, %s, %s, %s}, {%s, %s, %s, %s}, {%s, %s, %s, %s}, {0.0, 0.0}};\n", cn, C->kind, C->fn, C->aux,
+                     lit64(C->c0[0]).c_str(), lit64(C->c0[1]).c_str(), lit64(C->c0[2]).c_str(), lit64(C->c0[3]).c_str(),
+                     lit64(C->c1[0]).c_str(), lit64(C->c1[1]).c_str(), lit64(C->c1[2]).c_str(), lit64(C->c1[3]).c_str(),
+                     lit64(C->v[0]).c_str(), lit64(C->v[1]).c_str(), lit64(C->v[2]).c_str(), lit64(C->v[3]).c_str());
+                switch (C->kind) {
+                case EU_COL_UNIFORM: sf.f("            const Rgba %s = col_uniform(&%s);\n", v, cn); break;
+                case EU_COL_BLEND: {
+                    std::string dst = st.empty() ? "Rgba{}" : st.back(); if (!st.empty()) st.pop_back();
+                    std::string src = st.empty() ? "Rgba{}" : st.back(); if (!st.empty()) st.pop_back();
+                    sf.f("            const Rgba %s = col_blend(&%s, %s, %s);\n", v, cn, src.c_str(), dst.c_str());
+                    break;
+                }
+                case EU_COL_ILLUM_GLOBAL: sf.f("            const Rgba %s = col_illum_global<%d>(&%s, c);\n", v, D, cn); break;
+                case EU_COL_ILLUM_DIR: sf.f("            const Rgba %s = col_illum_dir<%d>(&%s, c);\n", v, D, cn); break;
+                case EU_COL_PERLIN: sf.f("            const Rgba %s = col_perlin<%d>(&%s, S.perlin(%uu), c, time_s);\n", v, D, cn, C->aux); break;
+                default: sf.f("            %s\n            const Rgba %s = mapped_get_color(&M%u, S.texels(%uu), c.loc, cnt);\n", mapped_record("M" + std::to_string(i), C->aux).c_str(), v, i, C->aux); break;
+                }
+                st.push_back(v);
+            }
+            sf.f("            return %s;\n        });\n    }\n", st.empty() ? "Rgba{}" : st.back().c_str());
+        }
+        sf.f("    static EU_DEV void surface(const EuScene &S, uint32_t ent, HitCtx<%d> &c, real time_s, LaneCounters &cnt, real *cst, uint32_t stride, SurfaceEval<%d> &E) {\n"
+             "        switch (ent) {\n", D, D);
+        for (auto &kv : by_surface) {
+            sf.f("       ");
+            for (uint32_t e : kv.second) sf.f(" case %uu:", e);
+            sf.f(" surf_%d(S, c, time_s, cnt, E); break;\n", kv.first);
+        }
+        sf.f("        default: E.ratio = R(0.0); E.have_color = false; E.translucent = false; E.spx = 0; E.sc = Rgba{R(0.0), R(0.0), R(0.0), R(0.0)}; break;\n        }\n    }\n");
+
+        /* ---- material_at (universe/mod.rs:229-251): first entity containing the point ---- */
+        Out ma;
+        ma.f("    static EU_DEV int material_at(const EuScene &S, const real *p) {\n");
+        for (uint32_t e = 0; e < ne; e++) { const EntityView E = entity(e); ma.f("        if (%s(S, p)) return %u;\n", inside_fn(E.shape_first, E.shape_root).c_str(), e); }
+        ma.f("        return -1;\n    }\n");
+
+        /* ---- Material::enter / exit of the material of entity `ent` ---- */
+        Out mp;
+        std::map<uint32_t, std::vector<uint32_t>> by_material;
+        for (uint32_t e = 0; e < ne; e++) by_material[entity(e).material].push_back(e);
+        mp.f("    static EU_DEV void material_apply(const EuScene &S, uint32_t ent, real *dir, bool exit_) {\n        switch (ent) {\n");
+        for (auto &kv : by_material) {
+            const uint64_t mw = w[h->off_materials + kv.first];
+            if (((uint32_t)mw & 0xff) != EU_MAT_LINEAR) continue;      /* Vacuum: enter and exit leave the direction alone (material.rs:32-57) */
+            mp.f("       ");
+            for (uint32_t e : kv.second) mp.f(" case %uu:", e);
+            mp.f("\n            if (!exit_) {\n");
+            emit_material(mp, kv.first, false, "                ");
+            mp.f("            } else {\n");
+            emit_material(mp, kv.first, true, "                ");
+            mp.f("            }\n            break;\n");
+        }
+        mp.f("        default: break;\n        }\n    }\n");
+
+        /* ---- background ---- */
+        Out bg;
+        bg.f("    static EU_DEV Rgba background(const EuScene &S, const real *point, LaneCounters &cnt) {\n        %s\n        return mapped_get_color(&M, S.texels(%uu), point, cnt);\n    }\n",
+             mapped_record("M", h->background).c_str(), h->background);
+
+        o.f("struct EuJit {\n    static constexpr bool kInterpreter = false;\n");
+        o.s += inside_defs;      /* (complete by now: every emitter above has registered the subtrees it tests) */
+        o.s += tc.s; o.s += hn.s; o.s += sf.s; o.s += ma.s; o.s += mp.s; o.s += bg.s;
+        o.f("};\n\n");
+    }
+};
+
+static std::string hex_digest(const std::string &a, const std::string &b) {
+    auto fnv = [](uint64_t seed, const std::string &s, uint64_t hsh) { hsh ^= seed; for (unsigned char c : s) { hsh ^= c; hsh *= 0x100000001b3ull; } return hsh; };
+    uint64_t h1 = fnv(0x1234567ull, a, 0xcbf29ce484222325ull), h2 = fnv(0x9e3779b97f4a7c15ull, a, 0x84222325cbf29ce4ull);
+    h1 = fnv(1, b, h1); h2 = fnv(2, b, h2);
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    return buf;
+}
+
+}  // namespace
+
+JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
+    JitPlan plan;
+    {
+        size_t i = 0;
+        while (i < extra_flags.size()) {
+            while (i < extra_flags.size() && extra_flags[i] == ' ') i++;
+            size_t j = i;
+            while (j < extra_flags.size() && extra_flags[j] != ' ') j++;
+            if (j > i) plan.extra_flags.push_back(extra_flags.substr(i, j - i));
+            i = j;
+        }
+    }
+    const EuFlatHeader &h = flat.header();
+    plan.dim = (int)h.dim;
+    /* the per-lane hit stack: in LDS while three workgroups per CU still fit (4 waves x cap x 64 lanes x (sizeof(real) + 4) bytes each),
+     * else a private array of exactly the entries this scene needs (the ahead-of-time kernels only have 16 and 96) */
+    const uint32_t cap = h.hit_cap < 8 ? 8u : ((h.hit_cap + 3u) & ~3u);
+    plan.hs_lds = h.hit_cap <= 32;
+    plan.hs_cap = cap;
+    Gen g(flat);
+    g.generate();
+    Out tail;
+    const unsigned hscap = plan.hs_lds ? 0u : cap;
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen,\n"
+           "        EuWfBuffers B, EuDevCounters *counters) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
+           "    wf_intersect_body<%d, %u, EuJit, false>(scene_g, hs_cap, gen, cam, fr, B, counters, nullptr, lds_dyn);\n}\n\n", plan.dim, hscap);
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect0(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,\n"
+           "        EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {\n    extern __shared__ uint64_t lds_dyn[];\n"
+           "    wf_intersect_body<%d, %u, EuJit, true>(scene_g, hs_cap, 0u, cam, fr, B, counters, hit_t_aov, lds_dyn);\n}\n\n", plan.dim, hscap);
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_shade(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, real time_s,\n"
+           "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
+           "    wf_shade_body<%d, false, EuJit, false>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn);\n}\n\n", plan.dim);
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_shade0(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,\n"
+           "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n"
+           "    wf_shade_body<%d, false, EuJit, true>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn);\n}\n", plan.dim);
+    plan.source = g.o.s + tail.s;
+    std::string dep = EU_JIT_VERSION;
+    for (const char *f : kCompileFlags) { dep += ' '; dep += f; }
+    for (const std::string &f : plan.extra_flags) { dep += ' '; dep += f; }
+    for (int k = 0; k < kNumHeaders; k++) { dep += kHeaders[k].name; dep += kHeaders[k].text; }
+    plan.key = hex_digest(plan.source, dep);
+    return plan;
+}
+
+/* ------------------------------------------------------------------ build + cache */
+static std::mutex g_mem_mutex;
+static std::map<std::string, std::vector<char>> g_mem_cache;      /* key -> code object (a process often creates several renderers of one scene) */
+
+static bool read_file(const std::string &path, std::vector<char> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<char> buf;
+    char tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    if (buf.size() < 64 || memcmp(buf.data(), "\x7f" "ELF", 4) != 0) return false;      /* a code object is an ELF file */
+    out.swap(buf);
+    return true;
+}
+
+static void mkdirs(const std::string &dir) {
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); i++) {
+        if (i == dir.size() || dir[i] == '/') { if (!cur.empty()) (void)mkdir(cur.c_str(), 0755); }
+        if (i < dir.size()) cur += dir[i];
+    }
+}
+
+static std::string default_cache_dir() {
+    if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/euclider_amd";
+    if (const char *hm = getenv("HOME")) if (*hm) return std::string(hm) + "/.cache/euclider_amd";
+    return "/tmp/euclider_amd_cache";
+}
+
+static std::string library_cache_dir() {      /* <directory of this shared library>/jit_cache */
+    Dl_info info;
+    if (dladdr((const void *)&default_cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s) + "/jit_cache";
+    }
+    return std::string();
+}
+
+int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out) {
+#if EU_REAL_BITS == 32
+    const std::string fname = plan.key + "_f32.hsaco";
+#else
+    const std::string fname = plan.key + ".hsaco";
+#endif
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        auto it = g_mem_cache.find(fname);
+        if (it != g_mem_cache.end()) { out.code = it->second; out.from_cache = true; return EU_OK; }
+    }
+    const std::string user_dir = cache_dir_in.empty() ? default_cache_dir() : cache_dir_in;
+    const std::string lib_dir = library_cache_dir();
+    for (const std::string &dir : {lib_dir, user_dir}) {
+        if (dir.empty()) continue;
+        if (read_file(dir + "/" + fname, out.code)) {
+            out.from_cache = true;
+            std::lock_guard<std::mutex> lk(g_mem_mutex);
+            g_mem_cache[fname] = out.code;
+            return EU_OK;
+        }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hiprtcProgram prog = nullptr;
+    std::vector<const char *> hdr_text, hdr_name;
+    for (int k = 0; k < kNumHeaders; k++) { hdr_text.push_back(kHeaders[k].text); hdr_name.push_back(kHeaders[k].name); }
+    hiprtcResult rc = hiprtcCreateProgram(&prog, plan.source.c_str(), "eu_jit_scene.hip", kNumHeaders, hdr_text.data(), hdr_name.data());
+    if (rc != HIPRTC_SUCCESS) { out.log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
+    std::vector<const char *> flags(kCompileFlags, kCompileFlags + sizeof(kCompileFlags) / sizeof(kCompileFlags[0]));
+    for (const std::string &f : plan.extra_flags) flags.push_back(f.c_str());
+    rc = hiprtcCompileProgram(prog, (int)flags.size(), flags.data());
+    size_t log_size = 0;
+    if (hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1) {
+        out.log.resize(log_size);
+        (void)hiprtcGetProgramLog(prog, &out.log[0]);
+    }
+    if (rc != HIPRTC_SUCCESS) {
+        out.log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(rc) + "\n" + out.log;
+        (void)hiprtcDestroyProgram(&prog);
+        return EU_ERR_HIP;
+    }
+    size_t code_size = 0;
+    rc = hiprtcGetCodeSize(prog, &code_size);
+    if (rc == HIPRTC_SUCCESS) { out.code.resize(code_size); rc = hiprtcGetCode(prog, out.code.data()); }
+    (void)hiprtcDestroyProgram(&prog);
+    if (rc != HIPRTC_SUCCESS || code_size == 0) { out.log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
+    out.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    out.from_cache = false;
+    {   /* keep it: atomically, so that a concurrent reader never sees half a file */
+        mkdirs(user_dir);
+        char tmpn[64];
+        snprintf(tmpn, sizeof tmpn, ".tmp.%ld.%p", (long)getpid(), (void *)&out);
+        const std::string tmp = user_dir + "/" + fname + tmpn, fin = user_dir + "/" + fname;
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (f) {
+            const bool ok = fwrite(out.code.data(), 1, out.code.size(), f) == out.code.size();
+            fclose(f);
+            if (!ok || rename(tmp.c_str(), fin.c_str()) != 0) (void)unlink(tmp.c_str());
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_mem_mutex);
+    g_mem_cache[fname] = out.code;
+    return EU_OK;
+}
+
+}  // namespace euclider

@@ -1,0 +1,49 @@
+/*
+ * jit.hpp -- scene-specialised trace kernels, generated and compiled when a renderer is created.
+ *
+ * The ahead-of-time kernels (trace_wavefront.h instantiated with EuInterp<D>) answer every question about the scene by
+ * walking the flat scene at run time: entity records, shape-program ops, colour programs and RPN code are decoded per ray
+ * batch (the reference does the same through trait objects and boxed iterators: /root/reference/src/universe/mod.rs:61-147,
+ * universe/entity/shape.rs:548-584).  For ONE scene all of that is known when the scene is loaded.  jit_generate_source()
+ * writes a scene policy (struct EuJit) in which every entity's shape program is a straight line of calls with constant kinds,
+ * counts and parameters, every surface a function with its provider records as constants, every LinearSpace expression an
+ * arithmetic expression; the same kernel bodies are instantiated with it and compiled by hiprtc for gfx950.  Both policies
+ * call the same arithmetic (trace_device.h), so the frames are bit-identical (tests/test_gpu_jit.py).
+ */
+#ifndef EU_JIT_HPP
+#define EU_JIT_HPP
+
+#include <string>
+#include <vector>
+
+#include "scene_host.hpp"
+
+namespace euclider {
+
+struct JitPlan {
+    int dim = 3;
+    bool hs_lds = true;          /* intersect kernel: per-lane hit stack in LDS (capacity hs_cap) or private (HSCAP = hs_cap entries) */
+    uint32_t hs_cap = 8;
+    std::string source;          /* HIP source of the translation unit */
+    std::vector<std::string> extra_flags;      /* caller's tuning flags (eu_renderer_opts.jit_flags), part of the key */
+    std::string key;             /* hex digest of everything the code object depends on */
+};
+
+/* Pure host code (no HIP call): the specialised translation unit for this scene. */
+JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags = std::string());
+
+struct JitBuild {
+    std::vector<char> code;      /* gfx950 code object */
+    bool from_cache = false;
+    double compile_ms = 0.0;
+    std::string log;
+};
+
+/* Compiles the plan with hiprtc (works without a GPU) or fetches the code object from the cache directories: `cache_dir`
+ * (read / write; empty: $XDG_CACHE_HOME/euclider_amd or ~/.cache/euclider_amd) and the read-only directory `jit_cache` next
+ * to the library (kernels compiled at build time travel with it).  Returns 0 or a negative EU_ERR_* code (log says why). */
+int jit_build(const JitPlan &plan, const std::string &cache_dir, JitBuild &out);
+
+}  // namespace euclider
+
+#endif

@@ -156,38 +156,38 @@ std::string Json::brief() const {
 }
 
 /* ------------------------------------------------------------------ vectors (nalgebra 0.8.2; x -> w order) */
-static double v_dot(int D, const double *a, const double *b) { double s = a[0] * b[0]; for (int i = 1; i < D; i++) s = s + a[i] * b[i]; return s; }
-static double v_nsq(int D, const double *a) { return v_dot(D, a, a); }
-static void v_normalize(int D, const double *a, double *o) { double n = sqrt(v_nsq(D, a)); for (int i = 0; i < D; i++) o[i] = a[i] / n; }
+static real v_dot(int D, const real *a, const real *b) { real s = a[0] * b[0]; for (int i = 1; i < D; i++) s = s + a[i] * b[i]; return s; }
+static real v_nsq(int D, const real *a) { return v_dot(D, a, a); }
+static void v_normalize(int D, const real *a, real *o) { real n = sqrt(v_nsq(D, a)); for (int i = 0; i < D; i++) o[i] = a[i] / n; }
 
 /* ------------------------------------------------------------------ shapes */
 ShapePtr VoidShape_new(int dim) { auto s = std::make_shared<Shape>(); s->kind = Shape::VoidShape; s->dim = dim; return s; }
 
-ShapePtr Sphere_new(int dim, const double *center, double radius) {           /* shape.rs:643-649 */
+ShapePtr Sphere_new(int dim, const real *center, real radius) {           /* shape.rs:643-649 */
     auto s = std::make_shared<Shape>(); s->kind = Shape::Sphere; s->dim = dim;
     for (int i = 0; i < dim; i++) s->a[i] = center[i];
     s->r = radius;
     return s;
 }
-ShapePtr Hyperplane_new(int dim, const double *normal, double constant) {     /* shape.rs:750-759 */
+ShapePtr Hyperplane_new(int dim, const real *normal, real constant) {     /* shape.rs:750-759 */
     if (!(v_nsq(dim, normal) > R(0.0))) fail(ParserError::CustomError, "Cannot have a normal with length of 0.");
     auto s = std::make_shared<Shape>(); s->kind = Shape::Hyperplane; s->dim = dim;
     for (int i = 0; i < dim; i++) s->a[i] = normal[i];
     s->r = constant;
     return s;
 }
-ShapePtr Hyperplane_new_with_point(int dim, const double *normal, const double *point) {   /* shape.rs:761-766 */
-    double constant = -v_dot(dim, normal, point);
+ShapePtr Hyperplane_new_with_point(int dim, const real *normal, const real *point) {   /* shape.rs:761-766 */
+    real constant = -v_dot(dim, normal, point);
     return Hyperplane_new(dim, normal, constant);
 }
-ShapePtr Hyperplane_new_with_vectors(const double *a, const double *b, const double *point) {   /* shape.rs:768-776 */
-    double n[MAXD] = {0, 0, 0, 0};
+ShapePtr Hyperplane_new_with_vectors(const real *a, const real *b, const real *point) {   /* shape.rs:768-776 */
+    real n[MAXD] = {0, 0, 0, 0};
     n[0] = a[1] * b[2] - a[2] * b[1];
     n[1] = a[2] * b[0] - a[0] * b[2];
     n[2] = a[0] * b[1] - a[1] * b[0];
     return Hyperplane_new_with_point(3, n, point);
 }
-ShapePtr HalfSpace_new(const ShapePtr &plane, double sign) {                  /* shape.rs:828-835 */
+ShapePtr HalfSpace_new(const ShapePtr &plane, real sign) {                  /* shape.rs:828-835 */
     if (!plane || plane->kind != Shape::Hyperplane)
         fail(ParserError::CustomError, std::string("Invalid type, expected a `Hyperplane") + (plane && plane->dim == 4 ? "4" : "3") + "`.");
     auto s = std::make_shared<Shape>(); s->kind = Shape::HalfSpace; s->dim = plane->dim;
@@ -196,10 +196,10 @@ ShapePtr HalfSpace_new(const ShapePtr &plane, double sign) {                  /*
     s->signum = sign / fabs(sign);
     return s;
 }
-ShapePtr HalfSpace_new_with_point(const ShapePtr &plane, const double *point) {   /* shape.rs:837-841 */
+ShapePtr HalfSpace_new_with_point(const ShapePtr &plane, const real *point) {   /* shape.rs:837-841 */
     if (!plane || plane->kind != Shape::Hyperplane)
         fail(ParserError::CustomError, std::string("Invalid type, expected a `Hyperplane") + (plane && plane->dim == 4 ? "4" : "3") + "`.");
-    double identifier = v_dot(plane->dim, plane->a, point) + plane->r;
+    real identifier = v_dot(plane->dim, plane->a, point) + plane->r;
     return HalfSpace_new(plane, identifier);
 }
 ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op) {   /* shape.rs:523-545: left fold */
@@ -212,24 +212,24 @@ ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op
     }
     return result;
 }
-static ShapePtr box_of_halfspaces(int D, const double *center, const double *abc) {
-    double half[MAXD];
+static ShapePtr box_of_halfspaces(int D, const real *center, const real *abc) {
+    real half[MAXD];
     for (int i = 0; i < D; i++) half[i] = abc[i] / R(2.0);
-    double axis[MAXD][MAXD] = {{0}};
+    real axis[MAXD][MAXD] = {{0}};
     for (int i = 0; i < D; i++) axis[i][i] = R(1.0);
     std::vector<ShapePtr> shapes;
     for (int ax = 0; ax < D; ax++) for (int neg = 0; neg < 2; neg++) {
-        double off[MAXD], pt[MAXD];
+        real off[MAXD], pt[MAXD];
         for (int i = 0; i < D; i++) off[i] = axis[ax][i] * half[i];            /* x * half_abc is component-wise */
         if (neg) for (int i = 0; i < D; i++) off[i] = -off[i];
         for (int i = 0; i < D; i++) pt[i] = center[i] + off[i];                /* na::translate(&v, &center) */
         ShapePtr plane;
         if (D == 3) {                                                          /* d3/entity/shape.rs:22-63 */
-            const double *va = (ax == 0) ? axis[1] : axis[0];
-            const double *vb = (ax == 2) ? axis[1] : axis[2];
+            const real *va = (ax == 0) ? axis[1] : axis[0];
+            const real *vb = (ax == 2) ? axis[1] : axis[2];
             plane = Hyperplane_new_with_vectors(va, vb, pt);
         } else {                                                               /* d4/entity/shape.rs:25-72 */
-            double nn[MAXD];
+            real nn[MAXD];
             v_normalize(D, axis[ax], nn);
             plane = Hyperplane_new_with_point(D, nn, pt);
         }
@@ -237,10 +237,10 @@ static ShapePtr box_of_halfspaces(int D, const double *center, const double *abc
     }
     return ComposableShape_of(shapes, SetOperation::Intersection);
 }
-ShapePtr HalfSpace_cuboid(const double *center, const double *abc) { return box_of_halfspaces(3, center, abc); }
-ShapePtr HalfSpace_hypercuboid(const double *center, const double *abcd) { return box_of_halfspaces(4, center, abcd); }
+ShapePtr HalfSpace_cuboid(const real *center, const real *abc) { return box_of_halfspaces(3, center, abc); }
+ShapePtr HalfSpace_hypercuboid(const real *center, const real *abcd) { return box_of_halfspaces(4, center, abcd); }
 
-ShapePtr Cylinder_new(int dim, const double *center, const double *direction, double radius) {   /* shape.rs:893-904 */
+ShapePtr Cylinder_new(int dim, const real *center, const real *direction, real radius) {   /* shape.rs:893-904 */
     if (!(v_nsq(dim, direction) > R(0.0))) fail(ParserError::CustomError, "Cannot have a direction with length of 0.");
     if (!(radius > R(0.0))) fail(ParserError::CustomError, "The radius must be positive.");
     auto s = std::make_shared<Shape>(); s->kind = Shape::Cylinder; s->dim = dim;
@@ -249,22 +249,22 @@ ShapePtr Cylinder_new(int dim, const double *center, const double *direction, do
     s->r = radius;
     return s;
 }
-ShapePtr Cylinder_new_with_height(int dim, const double *center, const double *direction, double radius, double height) {   /* shape.rs:906-927 */
-    double nd[MAXD], pt[MAXD];
+ShapePtr Cylinder_new_with_height(int dim, const real *center, const real *direction, real radius, real height) {   /* shape.rs:906-927 */
+    real nd[MAXD], pt[MAXD];
     v_normalize(dim, direction, nd);
-    double half_height = height / (R(1.0) + R(1.0));
+    real half_height = height / (R(1.0) + R(1.0));
     std::vector<ShapePtr> shapes;
     shapes.push_back(Cylinder_new(dim, center, direction, radius));
     for (int i = 0; i < dim; i++) pt[i] = center[i] + nd[i] * half_height;
     shapes.push_back(HalfSpace_new_with_point(Hyperplane_new_with_point(dim, nd, pt), center));
-    double neg_half = -half_height;
+    real neg_half = -half_height;
     for (int i = 0; i < dim; i++) pt[i] = center[i] + nd[i] * neg_half;
     shapes.push_back(HalfSpace_new_with_point(Hyperplane_new_with_point(dim, nd, pt), center));
     return ComposableShape_of(shapes, SetOperation::Intersection);
 }
 
 /* ------------------------------------------------------------------ misc constructors */
-eu_camera default_camera(int dim, const double *loc) {   /* d3/entity/camera.rs:42-52, d4/entity/camera.rs:47-58 */
+eu_camera default_camera(int dim, const real *loc) {   /* d3/entity/camera.rs:42-52, d4/entity/camera.rs:47-58 */
     eu_camera c;
     memset(&c, 0, sizeof c);
     c.dim = dim;
@@ -278,17 +278,17 @@ eu_camera default_camera(int dim, const double *loc) {   /* d3/entity/camera.rs:
 }
 
 /* palette 0.2.1 Hsv -> Rgb with RgbHue::to_positive_degrees (UNVERIFIED third-party semantics) */
-void rgba_from_hsva(double hue, double saturation, double value, double alpha, double *out) {
-    double deg = hue;
+void rgba_from_hsva(real hue, real saturation, real value, real alpha, real *out) {
+    real deg = hue;
     if (fabs(deg) < R(1.0e9)) {
         while (deg >= R(360.0)) deg = deg - R(360.0);
         while (deg < R(0.0)) deg = deg + R(360.0);
     }
-    double c = value * saturation;
-    double h = deg / R(60.0);
-    double x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
-    double m = value - c;
-    double r, g, b;
+    real c = value * saturation;
+    real h = deg / R(60.0);
+    real x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
+    real m = value - c;
+    real r, g, b;
     if (h >= R(0.0) && h < R(1.0)) { r = c; g = x; b = R(0.0); }
     else if (h >= R(1.0) && h < R(2.0)) { r = x; g = c; b = R(0.0); }
     else if (h >= R(2.0) && h < R(3.0)) { r = R(0.0); g = c; b = x; }
@@ -428,9 +428,9 @@ static std::string ty_name(const Ty &x) {
     return s;
 }
 struct Value {
-    double num = R(0.0);
+    real num = R(0.0);
     std::string str;
-    std::array<double, 4> vec{{0, 0, 0, 0}};
+    std::array<real, 4> vec{{0, 0, 0, 0}};
     std::shared_ptr<void> obj;
     std::vector<Value> list;
 };
@@ -495,7 +495,7 @@ struct Parser_ {
             Value v; v.num = j.num; return v;
         }
         case T::U8: case T::U32: {
-            double lim = type.t == T::U8 ? R(255.0) : R(4294967295.0);
+            real lim = type.t == T::U8 ? R(255.0) : R(4294967295.0);
             if (j.type != Json::Number || !(j.num >= R(0.0) && j.num <= lim) || j.num != floor(j.num))
                 fail(ParserError::TypeMismatch, std::string("Expected `") + (type.t == T::U8 ? "8-bit unsigned integer" : "32-bit unsigned integer") + "`, could not parse from `" + j.brief() + "`.");
             Value v; v.num = j.num; return v;
@@ -543,7 +543,7 @@ struct Parser_ {
     void build_registry();
 };
 
-static const double *vp(const Value &v) { return v.vec.data(); }
+static const real *vp(const Value &v) { return v.vec.data(); }
 
 void Parser_::build_registry() {
     for (int d = 3; d <= 4; d++) {
@@ -717,7 +717,7 @@ namespace {
 struct Flattener {
     int D;
     std::vector<EuShapeOp> ops;
-    std::vector<double> params;
+    std::vector<real> params;
     std::vector<EuFlatEntity> entities;
     std::vector<EuFlatMaterial> materials;
     std::vector<uint64_t> transforms;     /* 8 words each */
@@ -768,7 +768,7 @@ struct Flattener {
         params.push_back(s.r);
         if (s.kind == Shape::HalfSpace) {
             params.push_back(s.signum);
-            double k = -s.signum;                                   /* shape.rs:860 normal *= -signum */
+            real k = -s.signum;                                   /* shape.rs:860 normal *= -signum */
             for (int i = 0; i < D; i++) params.push_back(s.a[i] * k);
         } else {                                                    /* Hyperplane: never "inside", normal as given */
             params.push_back(std::nan(""));
@@ -778,7 +778,7 @@ struct Flattener {
 
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
     static bool no_guards() { static const bool v = getenv("EU_NO_SKIP_OPS") != nullptr; return v; }      /* A/B diagnostics */
-    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false, double parent_r = INFINITY) {
+    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false, real parent_r = INFINITY) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
         op.first = (uint16_t)ops.size();
@@ -794,10 +794,10 @@ struct Flattener {
             {   /* the chain's own bounding sphere (axis-aligned boxes only), right after its leaves: c[D], r2, far2; r2 < 0: none */
                 Bound b;
                 if (s.operation == SetOperation::Intersection) b = box_bound(chain);
-                double cmax = R(0.0);
+                real cmax = R(0.0);
                 for (int i = 0; i < D; i++) cmax = std::max(cmax, fabs(b.c[i]));
                 const bool ok = b.ok && b.r > R(0.0) && cmax <= R(1.0e6) * b.r;
-                const double rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
+                const real rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
                 for (int i = 0; i < D; i++) params.push_back(ok ? b.c[i] : R(0.0));
                 params.push_back(ok ? rr * rr : -R(1.0));
                 params.push_back(ok ? EU_BOUND_FAR2 * rr * rr : R(0.0));
@@ -821,7 +821,7 @@ struct Flattener {
                     ops.push_back(sk);
                 }
             }
-            const double child_r = has_b ? std::min(parent_r, (double)sb_.r) : parent_r;
+            const real child_r = has_b ? std::min(parent_r, (real)sb_.r) : parent_r;
             uint32_t la = emit_shape(*s.sa, base_use, depth, false, child_r);
             uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1, false, child_r);
             if (skip_at != (size_t)-1) {
@@ -874,15 +874,15 @@ struct Flattener {
     }
 
     /* ---- conservative bounding spheres (exact culling, DESIGN.md "Culling") ---- */
-    struct Bound { bool ok = false; double c[MAXD] = {0, 0, 0, 0}; double r = R(0.0); };
-    std::vector<double> bounds;
+    struct Bound { bool ok = false; real c[MAXD] = {0, 0, 0, 0}; real r = R(0.0); };
+    std::vector<real> bounds;
 
     static Bound enclose(int D, const Bound &a, const Bound &b) {
         Bound o;
         if (!a.ok || !b.ok) return o;
-        double dist2 = R(0.0);
+        real dist2 = R(0.0);
         for (int i = 0; i < D; i++) dist2 += (a.c[i] - b.c[i]) * (a.c[i] - b.c[i]);
-        const double dist = sqrt(dist2);
+        const real dist = sqrt(dist2);
         if (dist + b.r <= a.r) return a;
         if (dist + a.r <= b.r) return b;
         o.ok = true;
@@ -894,18 +894,18 @@ struct Flattener {
     /* an Intersection chain of axis-aligned half-spaces that bounds every axis on both sides (cuboid, hypercuboid) */
     Bound box_bound(const std::vector<const Shape *> &leaves) const {
         Bound o;
-        double lo[MAXD], hi[MAXD]; bool has_lo[MAXD] = {false, false, false, false}, has_hi[MAXD] = {false, false, false, false};
+        real lo[MAXD], hi[MAXD]; bool has_lo[MAXD] = {false, false, false, false}, has_hi[MAXD] = {false, false, false, false};
         for (auto *s : leaves) {
             if (s->kind != Shape::HalfSpace || !(s->signum == R(1.0) || s->signum == -R(1.0))) return o;
             int axis = -1;
             for (int i = 0; i < D; i++) if (s->a[i] != R(0.0)) { if (axis >= 0) return o; axis = i; }
             if (axis < 0) return o;
-            const double sn = s->a[axis], edge = -s->r / sn;          /* inside <=> sign(sn*x + c) == signum */
+            const real sn = s->a[axis], edge = -s->r / sn;          /* inside <=> sign(sn*x + c) == signum */
             if (!std::isfinite(edge)) return o;
             if (s->signum * sn > R(0.0)) { if (!has_lo[axis] || edge > lo[axis]) lo[axis] = edge; has_lo[axis] = true; }
             else { if (!has_hi[axis] || edge < hi[axis]) hi[axis] = edge; has_hi[axis] = true; }
         }
-        double r2 = R(0.0);
+        real r2 = R(0.0);
         for (int i = 0; i < D; i++) {
             if (!has_lo[i] || !has_hi[i] || !(hi[i] >= lo[i])) return o;
             o.c[i] = (lo[i] + hi[i]) / R(2.0);
@@ -928,26 +928,26 @@ struct Flattener {
         const Shape *cyl = nullptr;
         for (auto *l : leaves) { if (l->kind == Shape::Cylinder) { if (cyl) return o; cyl = l; } else if (l->kind != Shape::HalfSpace) return o; }
         if (!cyl || !(cyl->r > R(0.0)) || !std::isfinite(cyl->r)) return o;
-        double u[MAXD], un = R(0.0);
+        real u[MAXD], un = R(0.0);
         for (int i = 0; i < D; i++) un += cyl->b[i] * cyl->b[i];
         un = sqrt(un);
         if (!(un > R(0.0)) || !std::isfinite(un)) return o;
         for (int i = 0; i < D; i++) u[i] = cyl->b[i] / un;
-        bool has_lo = false, has_hi = false; double lo = R(0.0), hi = R(0.0);
+        bool has_lo = false, has_hi = false; real lo = R(0.0), hi = R(0.0);
         for (auto *l : leaves) {
             if (l == cyl) continue;
             if (!(l->signum == R(1.0) || l->signum == -R(1.0))) return o;
-            double k1 = R(0.0), k0 = l->r, nn = R(0.0);
+            real k1 = R(0.0), k0 = l->r, nn = R(0.0);
             for (int i = 0; i < D; i++) { k1 += l->a[i] * u[i]; k0 += l->a[i] * cyl->a[i]; nn += l->a[i] * l->a[i]; }
-            double perp2 = nn - k1 * k1;                          /* the normal's part across the axis */
+            real perp2 = nn - k1 * k1;                          /* the normal's part across the axis */
             if (!(nn > R(0.0)) || !(perp2 <= R(1.0e-18) * nn) || k1 == R(0.0)) continue;      /* not a cap: ignored (it can only cut more away) */
-            const double edge = -k0 / k1;                          /* inside <=> sign(k0 + k1 * tau) == signum */
+            const real edge = -k0 / k1;                          /* inside <=> sign(k0 + k1 * tau) == signum */
             if (!std::isfinite(edge)) continue;
             if (l->signum * k1 > R(0.0)) { if (!has_lo || edge > lo) lo = edge; has_lo = true; }
             else { if (!has_hi || edge < hi) hi = edge; has_hi = true; }
         }
         if (!has_lo || !has_hi || !(hi > lo)) return o;
-        const double mid = (lo + hi) / R(2.0), half = (hi - lo) / R(2.0);
+        const real mid = (lo + hi) / R(2.0), half = (hi - lo) / R(2.0);
         for (int i = 0; i < D; i++) o.c[i] = cyl->a[i] + u[i] * mid;
         o.r = sqrt(cyl->r * cyl->r + half * half);
         o.ok = std::isfinite(o.r);
@@ -981,10 +981,10 @@ struct Flattener {
     uint32_t entity_bound(const Shape &s) { return register_bound(shape_bound(s)); }
     uint32_t register_bound(const Bound &b) {
         if (!b.ok || !(b.r > R(0.0))) return 0xffffffffu;
-        double cmax = R(0.0);
+        real cmax = R(0.0);
         for (int i = 0; i < D; i++) { if (!std::isfinite(b.c[i])) return 0xffffffffu; cmax = std::max(cmax, fabs(b.c[i])); }
         if (cmax > R(1.0e6) * b.r) return 0xffffffffu;          /* the margin below must dominate rounding of |o - c|^2 */
-        const double rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
+        const real rr = b.r * (R(1.0) + EU_BOUND_REL) + EU_BOUND_ABS * std::max(R(1.0), cmax);
         uint32_t id = (uint32_t)(bounds.size() / (size_t)(D + 2));
         for (int i = 0; i < D; i++) bounds.push_back(b.c[i]);
         bounds.push_back(rr * rr);
@@ -1043,7 +1043,7 @@ struct Flattener {
         fm.tex_kind = m->texture->kind; fm.uv_kind = 0;
         fm.w = m->texture->w; fm.h = m->texture->h; fm.texels = 0;
         for (int i = 0; i < 3; i++) fm.center[i] = m->uvfn->center[i];
-        fm.wd = (double)fm.w; fm.hd = (double)fm.h;
+        fm.wd = (real)fm.w; fm.hd = (real)fm.h;
         uint32_t id = (uint32_t)mapped.size();
         mapped.push_back(fm); textures.push_back(m->texture);
         mapped_ids[m.get()] = id;
@@ -1128,7 +1128,7 @@ FlatScene flatten(const Universe &u) {
         fe.shape_first = (uint16_t)f.ops.size();
         {
             const auto eb = f.shape_bound(*e->shape);
-            f.emit_shape(*e->shape, 0, 0, true, eb.ok && eb.r > R(0.0) ? (double)eb.r : (double)INFINITY);
+            f.emit_shape(*e->shape, 0, 0, true, eb.ok && eb.r > R(0.0) ? (real)eb.r : (real)INFINITY);
         }
         fe.shape_root = (uint16_t)(f.ops.size() - 1);
         fe.max_hits = f.hit_cap;

@@ -63,10 +63,10 @@ enum class SetOperation { Union = 0, Intersection = 1, Complement = 2, Symmetric
 struct Shape {
     enum Kind { VoidShape, Sphere, Hyperplane, HalfSpace, Cylinder, ComposableShape } kind = VoidShape;
     int dim = 3;
-    double a[MAXD] = {0, 0, 0, 0};   /* sphere centre | plane normal | cylinder centre */
-    double b[MAXD] = {0, 0, 0, 0};   /* cylinder axis (normalised) */
-    double r = R(0.0);                  /* radius | plane constant */
-    double signum = R(0.0);             /* HalfSpace */
+    real a[MAXD] = {0, 0, 0, 0};   /* sphere centre | plane normal | cylinder centre */
+    real b[MAXD] = {0, 0, 0, 0};   /* cylinder axis (normalised) */
+    real r = R(0.0);                  /* radius | plane constant */
+    real signum = R(0.0);             /* HalfSpace */
     SetOperation operation = SetOperation::Union;
     std::shared_ptr<Shape> sa, sb;
 };
@@ -74,16 +74,16 @@ using ShapePtr = std::shared_ptr<Shape>;
 
 /* constructors, named after the reference's */
 ShapePtr VoidShape_new(int dim);
-ShapePtr Sphere_new(int dim, const double *center, double radius);
-ShapePtr Hyperplane_new(int dim, const double *normal, double constant);
-ShapePtr Hyperplane_new_with_point(int dim, const double *normal, const double *point);
-ShapePtr Hyperplane_new_with_vectors(const double *a, const double *b, const double *point);   /* 3-D */
-ShapePtr HalfSpace_new(const ShapePtr &plane, double sign);
-ShapePtr HalfSpace_new_with_point(const ShapePtr &plane, const double *point);
-ShapePtr HalfSpace_cuboid(const double *center, const double *abc);          /* d3::cuboid */
-ShapePtr HalfSpace_hypercuboid(const double *center, const double *abcd);    /* d4::hypercuboid */
-ShapePtr Cylinder_new(int dim, const double *center, const double *direction, double radius);
-ShapePtr Cylinder_new_with_height(int dim, const double *center, const double *direction, double radius, double height);
+ShapePtr Sphere_new(int dim, const real *center, real radius);
+ShapePtr Hyperplane_new(int dim, const real *normal, real constant);
+ShapePtr Hyperplane_new_with_point(int dim, const real *normal, const real *point);
+ShapePtr Hyperplane_new_with_vectors(const real *a, const real *b, const real *point);   /* 3-D */
+ShapePtr HalfSpace_new(const ShapePtr &plane, real sign);
+ShapePtr HalfSpace_new_with_point(const ShapePtr &plane, const real *point);
+ShapePtr HalfSpace_cuboid(const real *center, const real *abc);          /* d3::cuboid */
+ShapePtr HalfSpace_hypercuboid(const real *center, const real *abcd);    /* d4::hypercuboid */
+ShapePtr Cylinder_new(int dim, const real *center, const real *direction, real radius);
+ShapePtr Cylinder_new_with_height(int dim, const real *center, const real *direction, real radius, real height);
 ShapePtr ComposableShape_of(const std::vector<ShapePtr> &shapes, SetOperation op);
 
 /* meval-subset expression compiled to RPN words (flat_scene.h EuRpn) */
@@ -106,22 +106,22 @@ struct Material {
 using MaterialPtr = std::shared_ptr<Material>;
 
 struct Texture { uint32_t kind = 0, w = 0, h = 0; std::shared_ptr<std::vector<uint8_t>> rgba; std::string path; };
-struct UVFn { int dim = 3; double center[3] = {0, 0, 0}; };   /* uv_sphere_3, optionally wrapped by uv_derank_4 */
+struct UVFn { int dim = 3; real center[3] = {0, 0, 0}; };   /* uv_sphere_3, optionally wrapped by uv_derank_4 */
 struct MappedTexture { int dim = 3; std::shared_ptr<UVFn> uvfn; std::shared_ptr<Texture> texture; };
 
-struct BlendFunction { uint32_t fn = 0; double ratio = R(0.0); };
+struct BlendFunction { uint32_t fn = 0; real ratio = R(0.0); };
 struct SurfaceColor {
     uint32_t kind = 0;                 /* EuColorKind */
     int dim = 3;
-    double c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+    real c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
     std::shared_ptr<SurfaceColor> source, destination;
     std::shared_ptr<BlendFunction> blend;
     uint32_t seed = 0;
     std::shared_ptr<MappedTexture> mapped;
 };
-struct ReflectionRatio { uint32_t kind = 0; double p0 = 0, p1 = 0; };
+struct ReflectionRatio { uint32_t kind = 0; real p0 = 0, p1 = 0; };
 struct ReflectionDirection {};
-struct ThresholdDirection { uint32_t kind = 0; double p0 = 0; };
+struct ThresholdDirection { uint32_t kind = 0; real p0 = 0; };
 struct ComposableSurface {
     std::shared_ptr<ReflectionRatio> reflection_ratio;
     std::shared_ptr<ReflectionDirection> reflection_direction;
@@ -141,8 +141,8 @@ struct Universe {
     std::shared_ptr<MappedTexture> background;
 };
 
-eu_camera default_camera(int dim, const double *location_or_null);
-void rgba_from_hsva(double hue, double saturation, double value, double alpha, double *out);
+eu_camera default_camera(int dim, const real *location_or_null);
+void rgba_from_hsva(real hue, real saturation, real value, real alpha, real *out);
 void procedural_uv_grid(uint32_t w, uint32_t h, std::vector<uint8_t> &rgba);
 
 /* ---- the parser (scene.rs:554-1478) ---- */

@@ -23,9 +23,7 @@
 #ifndef EU_TRACE_DEVICE_H
 #define EU_TRACE_DEVICE_H
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
+#include "eu_platform.h"
 #include "eu_math.h"
 #include "flat_scene.h"
 #include "eu_real.h"      /* after the headers whose doubles stay doubles: the elementary functions and the flat record structs */
@@ -38,8 +36,8 @@
 #define EU_EPS R(1.0e-6) /* nalgebra 0.8.2 approx_epsilon (UNVERIFIED), surface.rs:84,133 */
 
 struct EuDevCamera {
-    double location[4], forward[4], up[4], right[4];
-    double dist;            /* sqrt(w*w+h*h) / (2 tan(fov/2)), camera.rs:176-179 */
+    real location[4], forward[4], up[4], right[4];
+    real dist;            /* sqrt(w*w+h*h) / (2 tan(fov/2)), camera.rs:176-179 */
     uint32_t max_depth, pad;
 };
 
@@ -49,7 +47,7 @@ struct EuDevFrame {
     uint32_t single_x, single_y;
     uint32_t local_rows, strip_count, strip_index, pad;   /* rows in the output buffer; interleaved-strip partition */
     uint32_t band_row0, band_rows, root_base, pad2;        /* wavefront: the band of local rows traced by this pass; root_base = band_row0 * width */
-    double time_s;          /* time_millis, d3/entity/surface.rs:32 */
+    real time_s;          /* time_millis, d3/entity/surface.rs:32 */
 };
 
 struct EuDevCounters {      /* device memory, zeroed before each launch */
@@ -82,7 +80,7 @@ struct EuScene {
         uint64_t x = w[off_ops + i];
         kind = (uint32_t)(x & 0xff); count = (uint32_t)((x >> 8) & 0xff); first = (uint32_t)((x >> 16) & 0xffff); param = (uint32_t)(x >> 32);
     }
-    EU_DEV const double *params(uint32_t off) const { return (const double *)(w + off_params) + off; }      /* offsets count elements of F */
+    EU_DEV const real *params(uint32_t off) const { return (const real *)(w + off_params) + off; }      /* offsets count elements of F */
     /* EuFlatEntity by value, unpacked from two 64-bit words: there are no sub-dword scalar loads, a 16-bit field read through
      * a pointer becomes a VECTOR load followed by s_waitcnt vmcnt(0) -- a full memory drain per entity of the intersect loop */
     struct EntityView { uint32_t shape_first, shape_root, material; int32_t surface; uint32_t max_hits, bound; };
@@ -95,44 +93,44 @@ struct EuScene {
     EU_DEV const EuFlatColorOp *color_op(uint32_t c) const { return (const EuFlatColorOp *)(w + off_color_ops + 16 * c); }
     EU_DEV const EuFlatMapped *mapped(uint32_t m) const { return (const EuFlatMapped *)(w + off_mapped + 8 * m); }
     EU_DEV uint64_t texels(uint32_t m) const { return ((const EuFlatMapped *)(wrt + off_mapped + 8 * m))->texels; }
-    EU_DEV const double *bounds(uint32_t b, int D) const { return (const double *)(w + off_bounds) + (uint32_t)(D + 2) * b; }
+    EU_DEV const real *bounds(uint32_t b, int D) const { return (const real *)(w + off_bounds) + (uint32_t)(D + 2) * b; }
     EU_DEV const uint8_t *perlin(uint32_t p) const { return (const uint8_t *)(w + off_perlin + 64 * p); }
 };
 
 /* ------------------------------------------------------------------ vectors (x -> w summation order) */
-template <int D> EU_DEV double vdot(const double *a, const double *b) {
-    double s = a[0] * b[0];
+template <int D> EU_DEV real vdot(const real *a, const real *b) {
+    real s = a[0] * b[0];
 #pragma unroll
     for (int i = 1; i < D; i++) s = s + a[i] * b[i];
     return s;
 }
-template <int D> EU_DEV double vnsq(const double *a) { return vdot<D>(a, a); }
-template <int D> EU_DEV double vnorm(const double *a) { return sqrt(vnsq<D>(a)); }
-template <int D> EU_DEV void vnormalize(const double *a, double *o) {
-    double n = vnorm<D>(a);
+template <int D> EU_DEV real vnsq(const real *a) { return vdot<D>(a, a); }
+template <int D> EU_DEV real vnorm(const real *a) { return sqrt(vnsq<D>(a)); }
+template <int D> EU_DEV void vnormalize(const real *a, real *o) {
+    real n = vnorm<D>(a);
 #pragma unroll
     for (int i = 0; i < D; i++) o[i] = a[i] / n;
 }
-template <int D> EU_DEV double angle_between(const double *a, const double *b) {   /* util.rs:712-722 */
-    double r = eu_acos(vdot<D>(a, b) / (vnorm<D>(a) * vnorm<D>(b)));
+template <int D> EU_DEV real angle_between(const real *a, const real *b) {   /* util.rs:712-722 */
+    real r = eu_acos(vdot<D>(a, b) / (vnorm<D>(a) * vnorm<D>(b)));
     return (r != r) ? R(0.0) : r;
 }
-EU_DEV double rust_signum(double x) { if (x != x) return x; return (eu_hi((eu_f64)x) >> 31) ? -R(1.0) : R(1.0); }      /* (widening keeps the sign, of zeros too) */
-EU_DEV double rust_min(double a, double b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
-EU_DEV double rust_max(double a, double b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
-EU_DEV double clamp01(double v) { if (v < R(0.0)) return R(0.0); if (v > R(1.0)) return R(1.0); return v; }
+EU_DEV real rust_signum(real x) { if (x != x) return x; return (eu_hi((eu_f64)x) >> 31) ? -R(1.0) : R(1.0); }      /* (widening keeps the sign, of zeros too) */
+EU_DEV real rust_min(real a, real b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
+EU_DEV real rust_max(real a, real b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
+EU_DEV real clamp01(real v) { if (v < R(0.0)) return R(0.0); if (v > R(1.0)) return R(1.0); return v; }
 #if EU_REAL_BITS == 32
-EU_DEV bool is_normal_f64(double x) { uint32_t e = (__float_as_uint(x) >> 23) & 0xffu; return e != 0 && e != 0xffu; }      /* f32::is_normal */
+EU_DEV bool is_normal_f64(real x) { uint32_t e = (__float_as_uint(x) >> 23) & 0xffu; return e != 0 && e != 0xffu; }      /* f32::is_normal */
 #else
-EU_DEV bool is_normal_f64(double x) { uint32_t e = (eu_hi(x) >> 20) & 0x7ff; return e != 0 && e != 0x7ff; }
+EU_DEV bool is_normal_f64(real x) { uint32_t e = (eu_hi(x) >> 20) & 0x7ff; return e != 0 && e != 0x7ff; }
 #endif
-EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
+EU_DEV real remainder_f(real a, real b) {   /* util.rs:287-299 */
     /* fmod is exact by definition (a - trunc(a / b) * b, no rounding).  The texture coordinates it is used on lie within two periods:
      * |a| < b gives a itself; b <= |a| < 2 b gives a -+ b, which is exact as well (Sterbenz: the operands are within a factor of two);
      * the sign of a zero result does not matter (normalised to +0 below).  Anything else (NaN, b <= 0, further away) takes the library
      * routine, a software loop of ~80 instructions, four times per texture sample before. */
-    double rem;
-    const double aa = fabs(a);
+    real rem;
+    const real aa = fabs(a);
     if (aa < b) rem = a;
     else if (aa < b + b) rem = a < R(0.0) ? a + b : a - b;
     else rem = fmod(a, b);
@@ -143,15 +141,15 @@ EU_DEV double remainder_f(double a, double b) {   /* util.rs:287-299 */
 
 /* ------------------------------------------------------------------ leaves */
 /* sphere (shape.rs:667-693) and cylinder (shape.rs:962-988) share the root selection */
-struct LeafHits { int n; double t0, t1; };      /* returned by value: reference out-parameters ended up in scratch memory */
+struct LeafHits { int n; real t0, t1; };      /* returned by value: reference out-parameters ended up in scratch memory */
 
-EU_DEV LeafHits quad_roots(double a, double b, double c) {
+EU_DEV LeafHits quad_roots(real a, real b, real c) {
     LeafHits r = {0, R(0.0), R(0.0)};
-    double d = b * b - R(4.0) * a * c;
+    real d = b * b - R(4.0) * a * c;
     if (d < R(0.0)) return r;
-    double d_sqrt = sqrt(d);
-    double t1 = (-b - d_sqrt) / (R(2.0) * a);
-    double t2 = (-b + d_sqrt) / (R(2.0) * a);
+    real d_sqrt = sqrt(d);
+    real t1 = (-b - d_sqrt) / (R(2.0) * a);
+    real t2 = (-b + d_sqrt) / (R(2.0) * a);
     if (t1 >= R(0.0)) {
         r.t0 = t1; r.n = 1;
         if (t2 >= R(0.0)) { r.t1 = t2; r.n = 2; }
@@ -159,69 +157,69 @@ EU_DEV LeafHits quad_roots(double a, double b, double c) {
     return r;
 }
 
-template <int D> EU_DEV LeafHits leaf_hits(uint32_t kind, const double *P, const double *o, const double *d) {
+template <int D> EU_DEV LeafHits leaf_hits(uint32_t kind, const real *P, const real *o, const real *d) {
     LeafHits none = {0, R(0.0), R(0.0)};
     switch (kind) {
     case EU_SH_SPHERE: {                                  /* shape.rs:652-731 */
-        double rel[D];
+        real rel[D];
 #pragma unroll
         for (int i = 0; i < D; i++) rel[i] = o[i] - P[i];
-        double a = vnsq<D>(d);
-        double b = R(2.0) * vdot<D>(d, rel);
-        double c = vnsq<D>(rel) - P[D + 1];
+        real a = vnsq<D>(d);
+        real b = R(2.0) * vdot<D>(d, rel);
+        real c = vnsq<D>(rel) - P[D + 1];
         return quad_roots(a, b, c);
     }
     case EU_SH_PLANE: case EU_SH_HALFSPACE: {             /* shape.rs:779-809, 843-870 */
-        double t = -(vdot<D>(P, o) + P[D]) / vdot<D>(P, d);
+        real t = -(vdot<D>(P, o) + P[D]) / vdot<D>(P, d);
         if (t < R(0.0)) return none;
         LeafHits r = {1, t, R(0.0)};
         return r;
     }
     case EU_SH_CYLINDER: {                                /* shape.rs:935-1027 */
-        const double *ax = P + D;
-        double a_vec[D], delta[D], c_vec[D];
-        double k = vdot<D>(d, ax);
+        const real *ax = P + D;
+        real a_vec[D], delta[D], c_vec[D];
+        real k = vdot<D>(d, ax);
 #pragma unroll
         for (int i = 0; i < D; i++) a_vec[i] = d[i] - ax[i] * k;
 #pragma unroll
         for (int i = 0; i < D; i++) delta[i] = o[i] - P[i];
-        double k2 = vdot<D>(delta, ax);
+        real k2 = vdot<D>(delta, ax);
 #pragma unroll
         for (int i = 0; i < D; i++) c_vec[i] = delta[i] - ax[i] * k2;
-        double a = vnsq<D>(a_vec);
-        double b = (R(1.0) + R(1.0)) * vdot<D>(a_vec, c_vec);
-        double c = vnsq<D>(c_vec) - P[2 * D + 1];
+        real a = vnsq<D>(a_vec);
+        real b = (R(1.0) + R(1.0)) * vdot<D>(a_vec, c_vec);
+        real c = vnsq<D>(c_vec) - P[2 * D + 1];
         return quad_roots(a, b, c);
     }
     default: return none;                                 /* VoidShape, shape.rs:622-631 */
     }
 }
 
-template <int D> EU_DEV void cyl_axis_point(const double *P, const double *to, double *out) {   /* shape.rs:929-932 */
-    const double *ax = P + D;
-    double dl[D];
+template <int D> EU_DEV void cyl_axis_point(const real *P, const real *to, real *out) {   /* shape.rs:929-932 */
+    const real *ax = P + D;
+    real dl[D];
 #pragma unroll
     for (int i = 0; i < D; i++) dl[i] = to[i] - P[i];
-    double k = vdot<D>(ax, dl);
+    real k = vdot<D>(ax, dl);
 #pragma unroll
     for (int i = 0; i < D; i++) out[i] = P[i] + ax[i] * k;
 }
 
-template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const double *p) {
+template <int D> EU_DEV bool leaf_inside(uint32_t kind, const real *P, const real *p) {
     switch (kind) {
     case EU_SH_VOID: return true;                         /* shape.rs:616-618 */
     case EU_SH_SPHERE: {                                  /* shape.rs:735-737 */
-        double dl[D];
+        real dl[D];
 #pragma unroll
         for (int i = 0; i < D; i++) dl[i] = P[i] - p[i];
         return vnsq<D>(dl) <= P[D + 1];
     }
     case EU_SH_HALFSPACE: {                               /* shape.rs:874-880 */
-        double result = vdot<D>(P, p) + P[D];
+        real result = vdot<D>(P, p) + P[D];
         return P[D + 1] == rust_signum(result);
     }
     case EU_SH_CYLINDER: {                                /* shape.rs:1032-1037 */
-        double q[D], v[D];
+        real q[D], v[D];
         cyl_axis_point<D>(P, p, q);
 #pragma unroll
         for (int i = 0; i < D; i++) v[i] = p[i] - q[i];
@@ -233,17 +231,23 @@ template <int D> EU_DEV bool leaf_inside(uint32_t kind, const double *P, const d
 
 /* ---- half-space chains (EU_SH_CHAIN_*): all leaves of a left-fold Union / Intersection are planes ---- */
 #define EU_HS_STRIDE(D) (2 * (D) + 2)
+/* The chain matrices are fully unrolled: up to 8 x 7 containment tests and 28 order tests, each a lane mask (an SGPR pair) until it is
+ * folded into its bit.  Left alone, the scheduler issues the comparisons of all rows first and spills the masks (v_writelane) by the
+ * hundred; a scheduling fence after every row keeps one row's masks alive at a time. */
+#ifndef EU_ROW_FENCE
+#define EU_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 /* is_point_inside of an EU_SH_CHAIN_BOX (see chain_matrices_box for why one product replaces the dot product) */
-EU_DEV bool is_neg_zero(double x) { return x == R(0.0) && (eu_hi((eu_f64)x) >> 31) != 0u; }
-template <int D, bool ZC = false> EU_DEV bool chain_inside_box(const double *P, const double *p) {
+EU_DEV bool is_neg_zero(real x) { return x == R(0.0) && (eu_hi((eu_f64)x) >> 31) != 0u; }
+template <int D, bool ZC = false> EU_DEV bool chain_inside_box(const real *P, const real *p) {
     bool finite = true;
 #pragma unroll
     for (int m = 0; m < D; m++) finite = finite && __builtin_isfinite(p[m]);
     if constexpr (ZC) {      /* EU_SH_CHAIN_BOX0: next to a zero constant a product of -0 is the one case the short form gets wrong: the long form then */
 #pragma unroll
         for (uint32_t k = 0; k < 2 * D; k++) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
+            const real *Pk = P + k * EU_HS_STRIDE(D);
             if (Pk[D] == R(0.0) && is_neg_zero(Pk[k / 2] * p[k / 2])) finite = false;
         }
     }
@@ -251,28 +255,28 @@ template <int D, bool ZC = false> EU_DEV bool chain_inside_box(const double *P, 
     if (finite) {
 #pragma unroll
         for (uint32_t k = 0; k < 2 * D; k++) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double r = Pk[k / 2] * p[k / 2] + Pk[D];
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real r = Pk[k / 2] * p[k / 2] + Pk[D];
             acc = acc && (Pk[D + 1] == rust_signum(r));
         }
     } else {
 #pragma unroll
         for (uint32_t k = 0; k < 2 * D; k++) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double r = vdot<D>(Pk, p) + Pk[D];
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real r = vdot<D>(Pk, p) + Pk[D];
             acc = acc && (Pk[D + 1] == rust_signum(r));
         }
     }
     return acc;
 }
 
-template <int D> EU_DEV bool chain_inside(bool is_union, uint32_t n, const double *P, const double *p) {
+template <int D> EU_DEV bool chain_inside(bool is_union, uint32_t n, const real *P, const real *p) {
     bool acc = !is_union;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         if (k < n) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double r = vdot<D>(Pk, p) + Pk[D];
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real r = vdot<D>(Pk, p) + Pk[D];
             const bool in = (Pk[D + 1] == rust_signum(r));          /* shape.rs:874-880 */
             acc = is_union ? (acc || in) : (acc && in);             /* shape.rs:591-594, no short-circuit needed: pure */
         }
@@ -282,7 +286,7 @@ template <int D> EU_DEV bool chain_inside(bool is_union, uint32_t n, const doubl
 
 /* is_point_inside of the subtree ops[first..root] (shape.rs:589-600), evaluated without
  * short-circuit on a bit stack (the leaf tests are pure, so the result is the same) */
-template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, uint32_t root, const double *p) {
+template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, uint32_t root, const real *p) {
     uint64_t st = 0;
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, cnt;
@@ -295,10 +299,10 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
             } else if (kind == EU_SH_SKIP) {  /* guard of the bounded subtree ending at op f: a point outside its (enlarged) bounding sphere is in none of its
                                                * leaves' solids by a margin that dwarfs rounding; the walk stays wave-uniform: skipped only if no lane needs it */
                 if (f <= root) {              /* (a guard whose subtree reaches beyond `root` belongs to an enclosing subtree: not ours) */
-                    const double *Bd = S.bounds(param, D);
-                    double rr = R(0.0);
+                    const real *Bd = S.bounds(param, D);
+                    real rr = R(0.0);
 #pragma unroll
-                    for (int m = 0; m < D; m++) { const double q = p[m] - Bd[m]; rr = rr + q * q; }
+                    for (int m = 0; m < D; m++) { const real q = p[m] - Bd[m]; rr = rr + q * q; }
                     if (__ballot(!(rr > Bd[D])) == 0ull) { st <<= 1; i = f; }
                 }
             } else {
@@ -326,28 +330,28 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
 /* the per-lane hit stack: in LDS (lane-interleaved: entry k of lane l at [k*64 + l], conflict-free
  * ds_read/ds_write_b64) when the scene's static bound fits, else in private (scratch) memory */
 struct HitStackLds {
-    double *t; uint32_t *c; uint32_t cap;
-    EU_DEV double gt(uint32_t k) const { return t[k * 64]; }
+    real *t; uint32_t *c; uint32_t cap;
+    EU_DEV real gt(uint32_t k) const { return t[k * 64]; }
     EU_DEV uint32_t gc(uint32_t k) const { return c[k * 64]; }
-    EU_DEV void set(uint32_t k, double tt, uint32_t cc) { t[k * 64] = tt; c[k * 64] = cc; }
-    EU_DEV void set_t(uint32_t k, double tt) { t[k * 64] = tt; }
+    EU_DEV void set(uint32_t k, real tt, uint32_t cc) { t[k * 64] = tt; c[k * 64] = cc; }
+    EU_DEV void set_t(uint32_t k, real tt) { t[k * 64] = tt; }
 };
 template <int CAP> struct HitStackPriv {
-    double t[CAP]; uint32_t c[CAP];
+    real t[CAP]; uint32_t c[CAP];
     static constexpr uint32_t cap = CAP;
-    EU_DEV double gt(uint32_t k) const { return t[k]; }
+    EU_DEV real gt(uint32_t k) const { return t[k]; }
     EU_DEV uint32_t gc(uint32_t k) const { return c[k]; }
-    EU_DEV void set(uint32_t k, double tt, uint32_t cc) { t[k] = tt; c[k] = cc; }
-    EU_DEV void set_t(uint32_t k, double tt) { t[k] = tt; }
+    EU_DEV void set(uint32_t k, real tt, uint32_t cc) { t[k] = tt; c[k] = cc; }
+    EU_DEV void set_t(uint32_t k, real tt) { t[k] = tt; }
 };
 
 enum { FR_OVER = 0, FR_TRANS_THEN_REFL = 1, FR_COMBINE = 2 };
 
 template <int D> struct FrameStack {
-    double ratio[EU_MAX_DEPTH];
+    real ratio[EU_MAX_DEPTH];
     uint32_t meta[EU_MAX_DEPTH];     /* kind | depth_of_second_child << 8 | entity << 16 */
     uint32_t px[EU_MAX_DEPTH];
-    double data[EU_MAX_DEPTH][2 * D];
+    real data[EU_MAX_DEPTH][2 * D];
 };
 
 #if defined(EU_PROFILE_SHAPE) || defined(EU_PROFILE_SHADE_WAVE)      /* diagnostic builds: s_memtime shares of eval_shape's parts (EU_PROFILE_SHAPE) or of the shade kernel's
@@ -367,7 +371,7 @@ struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
 #define SHP(c, k) do { } while (0)
 #endif
 
-struct Rgba { double r, g, b, a; };
+struct Rgba { real r, g, b, a; };
 
 /* ------------------------------------------------------------------ half-space chains: exact, branch-light evaluation
  *
@@ -382,8 +386,8 @@ struct Rgba { double r, g, b, a; };
  * single hit of leaf k, reproducing the iterator's three modes: both present (a failed test skips),
  * only a left (a failed test ends the stream), only b left. */
 template <int D>
-EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const double *d,
-                           double (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
+EU_DEV void chain_matrices(uint32_t n, const real *P, const real *o, const real *d,
+                           real (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
     /* Fully unrolled over the (at most 8) leaves with wave-uniform guards: the t_k and the hit points
      * stay in registers, plane parameters arrive through scalar loads (uniform addresses), and every
      * matrix entry costs one dot product, one compare and one bit insert. */
@@ -392,8 +396,8 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         tk[k] = R(0.0);
         if (k < n) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
             tk[k] = t;
             if (!(t < R(0.0))) pres |= 1u << k;
         }
@@ -404,18 +408,19 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
 #pragma unroll
     for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
         if (i < n && ((pres >> i) & 1u)) {      /* a leaf without a hit (t < 0) never enters a list: its row is never read (chain_merge) */
-            double loc[D];
+            real loc[D];
 #pragma unroll
             for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * tk[i];
 #pragma unroll
             for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
                 if (j < n && j != i) {
-                    const double *Pj = P + j * EU_HS_STRIDE(D);
-                    const double r = vdot<D>(Pj, loc) + Pj[D];
+                    const real *Pj = P + j * EU_HS_STRIDE(D);
+                    const real r = vdot<D>(Pj, loc) + Pj[D];
                     if (Pj[D + 1] == rust_signum(r)) in_k[j] |= 1u << i;       /* shape.rs:874-880 */
                     if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
                 }
             }
+            EU_ROW_FENCE();
         }
     }
     pres_out = pres;
@@ -438,7 +443,7 @@ EU_DEV void chain_matrices(uint32_t n, const double *P, const double *o, const d
  * and c_k is -0.  With c_k = +0 both are +0; with c_k = -0 they can differ only when the product s_k x_a is -0.  So the routine
  * reports false (and the wave is traced generically) whenever a product with a zero-constant leaf's normal is -0 -- a coordinate
  * that is exactly zero with the unlucky sign: it does not happen in practice and costs one comparison per use of such a leaf. */
-template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
+template <int D> EU_DEV bool ray_is_regular(const real *o, const real *d) {
     bool ok = true;
 #pragma unroll
     for (int m = 0; m < D; m++) ok = ok && __builtin_isfinite(o[m]) && __builtin_isfinite(d[m]) && d[m] != R(0.0);
@@ -446,8 +451,8 @@ template <int D> EU_DEV bool ray_is_regular(const double *o, const double *d) {
 }
 
 template <int D, bool ZC = false>
-EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d,
-                               double (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
+EU_DEV bool chain_matrices_box(const real *P, const real *o, const real *d,
+                               real (&tk)[EU_CHAIN_MAX], uint32_t &pres_out, uint32_t (&in_k)[EU_CHAIN_MAX], uint32_t (&lt_k)[EU_CHAIN_MAX]) {
     constexpr uint32_t n = 2 * D;
     bool ok = true;         /* the caller has checked the ray itself (ray_is_regular) */
     uint32_t pres = 0;
@@ -455,8 +460,8 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         tk[k] = R(0.0);
         if (k < n) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double t = -(Pk[k / 2] * o[k / 2] + Pk[D]) / (Pk[k / 2] * d[k / 2]);
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real t = -(Pk[k / 2] * o[k / 2] + Pk[D]) / (Pk[k / 2] * d[k / 2]);
             if constexpr (ZC) { if (Pk[D] == R(0.0) && is_neg_zero(Pk[k / 2] * o[k / 2])) ok = false; }
             tk[k] = t;
             if (!(t < R(0.0))) pres |= 1u << k;
@@ -467,14 +472,14 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
 #pragma unroll
     for (uint32_t i = 0; i < EU_CHAIN_MAX; i++) {
         if (i < n && ((pres >> i) & 1u)) {      /* (rows of leaves without a hit are never read) */
-            double loc[D];
+            real loc[D];
 #pragma unroll
             for (int m = 0; m < D; m++) { loc[m] = o[m] + d[m] * tk[i]; ok = ok && __builtin_isfinite(loc[m]); }
 #pragma unroll
             for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
                 if (j < n && j != i) {
-                    const double *Pj = P + j * EU_HS_STRIDE(D);
-                    const double r = Pj[j / 2] * loc[j / 2] + Pj[D];
+                    const real *Pj = P + j * EU_HS_STRIDE(D);
+                    const real r = Pj[j / 2] * loc[j / 2] + Pj[D];
                     if constexpr (ZC) { if (Pj[D] == R(0.0) && is_neg_zero(Pj[j / 2] * loc[j / 2])) ok = false; }
                     /* signum_j == rust_signum(r) (shape.rs:874-880): signum_j is +-1 (the loader only calls such chains boxes) and r is
                      * finite when loc is (else the result is discarded), so the two are equal exactly when their sign bits are */
@@ -482,6 +487,7 @@ EU_DEV bool chain_matrices_box(const double *P, const double *o, const double *d
                     if (i < j && tk[i] < tk[j]) lt_k[j] |= 1u << i;
                 }
             }
+            EU_ROW_FENCE();
         }
     }
     pres_out = pres;
@@ -537,8 +543,8 @@ EU_DEV uint32_t chain_merge(bool is_union, uint32_t n, uint32_t pres, const uint
 /* use_box (wave-uniform): an EU_SH_CHAIN_BOX goes through chain_matrices_box; a lane it cannot serve sets `fail` (its result is
  * then meaningless) and the caller traces the wave's rays again with use_box = false, where a box is an ordinary Intersection chain. */
 template <int D>
-EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const double *P, const double *o, const double *d,
-                           double (&tk)[EU_CHAIN_MAX], uint32_t &list_out, bool use_box, bool &fail, LaneCounters *prof = nullptr) {
+EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const real *P, const real *o, const real *d,
+                           real (&tk)[EU_CHAIN_MAX], uint32_t &list_out, bool use_box, bool &fail, LaneCounters *prof = nullptr) {
     uint32_t pres = 0, in_k[EU_CHAIN_MAX], lt_k[EU_CHAIN_MAX];
     if (use_box && kind == EU_SH_CHAIN_BOX) {      /* wave-uniform */
         if (!chain_matrices_box<D>(P, o, d, tk, pres, in_k, lt_k)) fail = true;
@@ -566,22 +572,22 @@ EU_DEV uint32_t eval_chain(uint32_t kind, uint32_t n, const double *P, const dou
  * No hit at all -> every stream is empty.  Anything else (a tie, a NaN t, a point inside another half-space) is left to
  * eval_chain.  Returns 1 (t_out, idx_out), 0 (empty) or -1 (undecided). */
 template <int D>
-EU_DEV int union_chain_first(uint32_t n, const double *P, const double *o, const double *d, double &t_out, uint32_t &idx_out) {
-    double tk[EU_CHAIN_MAX];
+EU_DEV int union_chain_first(uint32_t n, const real *P, const real *o, const real *d, real &t_out, uint32_t &idx_out) {
+    real tk[EU_CHAIN_MAX];
     uint32_t pres = 0;
     bool has_nan = false;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         tk[k] = R(0.0);
         if (k < n) {
-            const double *Pk = P + k * EU_HS_STRIDE(D);
-            const double t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
+            const real *Pk = P + k * EU_HS_STRIDE(D);
+            const real t = -(vdot<D>(Pk, o) + Pk[D]) / vdot<D>(Pk, d);      /* shape.rs:789-790 */
             tk[k] = t;
             if (!(t < R(0.0))) { pres |= 1u << k; if (t != t) has_nan = true; }
         }
     }
     if (pres == 0) return 0;
-    double best = R(0.0); uint32_t idx = 0; bool have = false;
+    real best = R(0.0); uint32_t idx = 0; bool have = false;
 #pragma unroll
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         if (k < n && ((pres >> k) & 1u) && (!have || tk[k] < best)) { best = tk[k]; idx = k; have = true; }
@@ -591,14 +597,14 @@ EU_DEV int union_chain_first(uint32_t n, const double *P, const double *o, const
     for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) {
         if (k < n && ((pres >> k) & 1u) && k != idx && !(best < tk[k])) ok = false;       /* a tie */
     }
-    double loc[D];
+    real loc[D];
 #pragma unroll
     for (int m = 0; m < D; m++) loc[m] = o[m] + d[m] * best;
 #pragma unroll
     for (uint32_t j = 0; j < EU_CHAIN_MAX; j++) {
         if (j < n) {
-            const double *Pj = P + j * EU_HS_STRIDE(D);
-            const double r = vdot<D>(Pj, loc) + Pj[D];
+            const real *Pj = P + j * EU_HS_STRIDE(D);
+            const real r = vdot<D>(Pj, loc) + Pj[D];
             if (j != idx && Pj[D + 1] == rust_signum(r)) ok = false;                        /* inside another half-space */
         }
     }
@@ -616,72 +622,213 @@ EU_DEV int union_chain_first(uint32_t n, const double *P, const double *o, const
  * The entity's stream is therefore empty and trace_closest would skip it anyway (universe/mod.rs:114):
  * skipping the evaluation changes nothing.  The same test is applied to every box chain inside a CSG tree
  * (its stream is empty, so an empty list is pushed without evaluating the chain).  NaN anywhere makes every comparison false: no culling. */
-template <int D> EU_DEV bool ray_misses_bound(const double *Bd, const double *o, const double *d) {
-    double rel[D];
+template <int D> EU_DEV bool ray_misses_bound(const real *Bd, const real *o, const real *d) {
+    real rel[D];
 #pragma unroll
     for (int i = 0; i < D; i++) rel[i] = o[i] - Bd[i];
-    const double rr = vdot<D>(rel, rel);
-    const double cc = rr - Bd[D];
+    const real rr = vdot<D>(rel, rel);
+    const real cc = rr - Bd[D];
     if (cc > R(0.0)) {                                   /* origin outside the enlarged sphere */
-        const double b = vdot<D>(d, rel);
+        const real b = vdot<D>(d, rel);
         if (b >= R(0.0)) return true;                    /* moving away: the closest point is the origin */
         if (rr < Bd[D + 1]) {                         /* discriminant margin only holds for |o-c| < 1e4 R */
-            const double a = vdot<D>(d, d);
+            const real a = vdot<D>(d, d);
             if (b * b - a * cc < R(0.0)) return true;    /* the whole line misses */
         }
     }
     return false;
 }
 
-/* ------------------------------------------------------------------ CSG: eager post-order evaluation */
+/* ------------------------------------------------------------------ CSG: eager post-order evaluation
+ * The pieces below are shared by the interpreter (eval_shape walks an entity's shape program op by op) and by the
+ * scene-specialised kernels (jit.cpp emits the same calls in a straight line, every kind, count and parameter a constant). */
+
+/* one evaluated hit list on the per-lane hit stack: n entries; rep: the stream repeats its last element for ever;
+ * unk: "unknown beyond" (see eval_shape) */
+struct CsgList { uint32_t n; bool rep, unk; };
+
+/* a bare leaf or chain that is a whole entity: element 0 of its stream, no list machinery (trace_closest only looks at
+ * element 0, universe/mod.rs:114).  P: the op's parameters (a chain's bounding sphere follows its leaves). */
+template <int D, class HS>
+EU_DEV uint32_t eval_single(uint32_t kind, uint32_t count, const real *P, const real *o, const real *d, HS &hs, uint32_t op_index,
+                            LaneCounters &cnt, real &first_t, uint32_t &first_c, bool use_box, bool &fail) {
+    SHP(cnt, 6);
+    if (kind >= EU_SH_CHAIN_UNION) {
+        real tk[EU_CHAIN_MAX]; uint32_t list;
+        const real *Pb = P + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
+        if (Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)) { SHP(cnt, 0); return 0u; }
+        SHP(cnt, 0);
+        if (kind == EU_SH_CHAIN_UNION) {
+            real tf = R(0.0); uint32_t idx = 0;
+            const int q = union_chain_first<D>(count, P, o, d, tf, idx);
+            SHP(cnt, 7);
+            if (q == 0) return 0u;
+            if (q > 0) { first_t = tf; first_c = op_index | (idx << 16); return 1u; }
+        }
+#ifdef EU_PROFILE_SHAPE
+        const uint32_t n = eval_chain<D>(kind, count, P, o, d, tk, list, use_box, fail, &cnt);
+#else
+        const uint32_t n = eval_chain<D>(kind, count, P, o, d, tk, list, use_box, fail);
+#endif
+        if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
+#pragma unroll
+            for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
+            first_t = hs.gt(list & 15u); first_c = op_index | ((list & 15u) << 16);
+        }
+        SHP(cnt, 3);
+        return n;
+    }
+    const LeafHits lh = leaf_hits<D>(kind, P, o, d);
+    if (lh.n) { first_t = lh.t0; first_c = op_index; }
+    SHP(cnt, 4);
+    return (uint32_t)lh.n;
+}
+
+/* the hits of a leaf op inside a tree: pushed at hs[sp ..) */
+template <int D, class HS>
+EU_DEV CsgList push_leaf(uint32_t kind, const real *P, const real *o, const real *d, HS &hs, uint32_t &sp, uint32_t op_index, LaneCounters &cnt) {
+    SHP(cnt, 6);
+    const LeafHits lh = leaf_hits<D>(kind, P, o, d);
+    int n = lh.n;
+    if (sp + 2 > hs.cap) { cnt.errors++; n = 0; }
+    if (n >= 1) hs.set(sp, lh.t0, op_index);
+    if (n >= 2) hs.set(sp + 1, lh.t1, op_index | EU_HIT_SECOND);
+    sp += (uint32_t)n;
+    SHP(cnt, 4);
+    return CsgList{(uint32_t)n, false, false};
+}
+
+/* the stream of a half-space chain op inside a tree */
+template <int D, class HS>
+EU_DEV CsgList push_chain(uint32_t kind, uint32_t count, const real *P, const real *o, const real *d, HS &hs, uint32_t &sp, uint32_t op_index,
+                          LaneCounters &cnt, bool use_box, bool &fail) {
+    real tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
+    const real *Pb = P + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
+    SHP(cnt, 6);
+    if (sp + 2 * count > hs.cap) cnt.errors++;          /* count slots for the list + count for the t_k */
+    else if (!(Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d))) {
+        SHP(cnt, 0);
+#ifdef EU_PROFILE_SHAPE
+        n = eval_chain<D>(kind, count, P, o, d, tk, list, use_box, fail, &cnt);
+#else
+        n = eval_chain<D>(kind, count, P, o, d, tk, list, use_box, fail);
+#endif
+    }
+    SHP(cnt, 0);
+    if (n) {
+#pragma unroll
+        for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
+    }
+    for (uint32_t p = 0; p < n; p++) {
+        const uint32_t idx = (list >> (4 * p)) & 15u;
+        hs.set(sp + p, hs.gt(sp + count + idx), op_index | (idx << 16));
+    }
+    sp += n;
+    SHP(cnt, 3);
+    return CsgList{n, false, false};
+}
+
+/* One composite op: merges the two topmost lists of the hit stack (A below B) the way the reference's four iterators do
+ * (shape.rs:188-497) and leaves the result in their place.  inside_a / inside_b: is_point_inside of the child subtrees
+ * (shape.rs:589-600).  The reference evaluates streams lazily and trace_closest only asks for element 0; this evaluation is
+ * eager.  Where the eager merge meets something the reference would never finish computing (a stream that neither ends nor
+ * yields), the list is cut there and marked "unknown beyond".  A parent that runs past such a cut inherits the mark; only an
+ * entity whose FIRST element is unknown counts as an error (the reference would spin). */
+template <int D, class HS, class InsA, class InsB>
+EU_DEV CsgList csg_merge(uint32_t kind, bool is_root, HS &hs, uint32_t &sp, const CsgList A, const CsgList B, const real *o, const real *d,
+                         LaneCounters &cnt, InsA inside_a, InsB inside_b) {
+    SHP(cnt, 6);
+    const uint32_t CAP = hs.cap;
+    const uint32_t nb = B.n, na = A.n;
+    const bool unk_a = A.unk, unk_b = B.unk;
+    bool out_unk = false;
+    const bool rep_a = A.rep && na > 0, rep_b = B.rep && nb > 0;
+    const uint32_t b0 = sp - nb, a0 = b0 - na, o0 = sp;
+    uint32_t ia = 0, ib = 0, no = 0;
+    bool out_rep = false;
+    const uint32_t guard_max = 4 * (na + nb) + 8;
+    for (uint32_t guard = 0;; guard++) {
+        const bool sa = ia < na || rep_a, sb = ib < nb || rep_b;
+        if ((!sa && unk_a) || (!sb && unk_b)) { out_unk = true; break; }      /* next() asks both children first (shape.rs:214-215 ...) */
+        if (!sa && !sb) break;
+        if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
+        real ta = R(0.0), tb = R(0.0); uint32_t ca = 0, cb = 0;
+        if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
+        if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
+        const bool both = sa && sb;
+        const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
+        if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
+            if (o0 + no >= CAP) { if (!(is_root && no > 0)) cnt.errors++; break; }  /* capacity (na + nb + 1; at the root only element 0 matters) */
+            hs.set(o0 + no, ta, ca); no++;
+            out_rep = true;
+            break;
+        }
+        /* consuming the repeated tail of a never-ending child stream leaves the iterator state
+         * unchanged: the same decision recurs forever */
+        const bool stuck = take_a ? (ia >= na) : (ib >= nb);
+        const real t = take_a ? ta : tb;
+        uint32_t c = take_a ? ca : cb;
+        real loc[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) loc[k] = o[k] + d[k] * t;
+        const bool ins = take_a ? inside_b(loc) : inside_a(loc);
+        if (take_a) ia++; else ib++;
+        bool emit = false, end = false;
+        switch (kind) {
+        case EU_SH_UNION:                                /* shape.rs:212-264 */
+            if (both) emit = !ins; else { if (ins) end = true; else emit = true; }
+            break;
+        case EU_SH_INTERSECTION:                         /* shape.rs:291-340 */
+            if (both) emit = ins; else { if (ins) emit = true; else end = true; }
+            break;
+        case EU_SH_COMPLEMENT:                           /* shape.rs:365-409 */
+            if (take_a) emit = !ins;                      /* only reachable with both present */
+            else { if (ins) { emit = true; c ^= EU_HIT_FLIP; } else if (!both) end = true; }
+            break;
+        default:                                         /* SymmetricDifference, shape.rs:436-496 */
+            emit = true;
+            if (ins) c ^= EU_HIT_FLIP;
+            break;
+        }
+        /* a decision taken on a repeated tail recurs forever with the same outcome (the state did not change): the
+         * element it would emit is the one emitted the step before, so the list is only marked as repeating */
+        if (stuck) { if (emit) out_rep = true; else if (!end) out_unk = true; break; }   /* no output and no end, forever: the reference would spin */
+        if (emit) {
+            if (o0 + no >= CAP) { if (!(is_root && no > 0)) cnt.errors++; break; }   /* capacity (the loader's bound is na + nb) */
+            hs.set(o0 + no, t, c); no++;
+            /* trace_closest asks an entity's stream for element 0 only (universe/mod.rs:114) and the reference's iterators are
+             * lazy: what the root's merge would produce after its first element is never computed there */
+            if (is_root) break;
+        }
+        if (end) break;
+    }
+    for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
+    SHP(cnt, 5);
+    sp = a0 + no;
+    return CsgList{no, out_rep, out_unk};
+}
+
+/* element 0 of a tree's root list (after its last csg_merge) */
+template <class HS>
+EU_DEV uint32_t csg_root_result(const CsgList L, HS &hs, LaneCounters &cnt, real &first_t, uint32_t &first_c) {
+    if (L.n) { first_t = hs.gt(0); first_c = hs.gc(0); }
+    else if (L.unk) cnt.errors++;          /* element 0 itself is something the reference never finishes computing */
+    return L.n;
+}
+
 /* Evaluates entity shape program ops[first..root] for ray (o, d); returns the number of hits of the
  * entity's stream and its first element (only that is used by trace_closest, universe/mod.rs:114). */
 template <int D, class HS>
-EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
-                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c, bool use_box, bool &fail) {
+EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const real *o, const real *d,
+                           HS &hs, LaneCounters &cnt, real &first_t, uint32_t &first_c, bool use_box, bool &fail) {
     if (first == root) {   /* a bare leaf or chain: no list machinery */
         uint32_t kind, f, param, count;
-        SHP(cnt, 6);
         S.op(root, kind, f, param, count);
-        if (kind >= EU_SH_CHAIN_UNION) {
-            double tk[EU_CHAIN_MAX]; uint32_t list;
-            const double *Pc = S.params(param);
-            const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
-            if (Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d)) { SHP(cnt, 0); return 0u; }
-            SHP(cnt, 0);
-            if (kind == EU_SH_CHAIN_UNION) {
-                double tf = R(0.0); uint32_t idx = 0;
-                const int q = union_chain_first<D>(count, Pc, o, d, tf, idx);
-                SHP(cnt, 7);
-                if (q == 0) return 0u;
-                if (q > 0) { first_t = tf; first_c = root | (idx << 16); return 1u; }
-            }
-#ifdef EU_PROFILE_SHAPE
-            const uint32_t n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail, &cnt);
-#else
-            const uint32_t n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
-#endif
-            if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
-#pragma unroll
-                for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
-                first_t = hs.gt(list & 15u); first_c = root | ((list & 15u) << 16);
-            }
-            SHP(cnt, 3);
-            return n;
-        }
-        const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
-        if (lh.n) { first_t = lh.t0; first_c = root; }
-        SHP(cnt, 4);
-        return (uint32_t)lh.n;
+        return eval_single<D>(kind, count, S.params(param), o, d, hs, root, cnt, first_t, first_c, use_box, fail);
     }
-    const uint32_t CAP = hs.cap;
     uint32_t sp = 0;          /* entries in use */
     uint64_t lens = 0;        /* stack of list lengths, 8 bits each (bit 7: stream repeats its last element forever) */
-    /* The reference evaluates streams lazily and trace_closest only asks for element 0; this evaluation is eager.  Where
-     * the eager merge meets something the reference would never finish computing (a stream that neither ends nor yields),
-     * the list is cut there and marked "unknown beyond" (one bit per stacked list).  A parent that runs past such a cut
-     * inherits the mark; only an entity whose FIRST element is unknown counts as an error (the reference would spin). */
-    uint32_t unk = 0;
+    uint32_t unk = 0;         /* "unknown beyond" marks, one bit per stacked list */
     for (uint32_t i = first; i <= root; i++) {
         uint32_t kind, f, param, count;
         S.op(i, kind, f, param, count);
@@ -690,48 +837,17 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
                 if (__ballot(!ray_misses_bound<D>(S.bounds(param, D), o, d)) == 0ull) { lens <<= 8; unk <<= 1; i = f; }
                 continue;
             }
-            double tk[EU_CHAIN_MAX]; uint32_t list = 0, n = 0;
-            const double *Pc = S.params(param);
-            const double *Pb = Pc + count * EU_HS_STRIDE(D);          /* the chain's bounding sphere (r2 < 0: none) */
-            SHP(cnt, 6);
-            if (sp + 2 * count > CAP) cnt.errors++;          /* count slots for the list + count for the t_k */
-            else if (!(Pb[D] >= R(0.0) && ray_misses_bound<D>(Pb, o, d))) {
-                SHP(cnt, 0);
-#ifdef EU_PROFILE_SHAPE
-                n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail, &cnt);
-#else
-                n = eval_chain<D>(kind, count, Pc, o, d, tk, list, use_box, fail);
-#endif
-            }
-            SHP(cnt, 0);
-            if (n) {
-#pragma unroll
-                for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
-            }
-            for (uint32_t p = 0; p < n; p++) {
-                const uint32_t idx = (list >> (4 * p)) & 15u;
-                hs.set(sp + p, hs.gt(sp + count + idx), i | (idx << 16));
-            }
-            sp += n;
-            lens = (lens << 8) | (uint64_t)n;
+            const CsgList L = push_chain<D>(kind, count, S.params(param), o, d, hs, sp, i, cnt, use_box, fail);
+            lens = (lens << 8) | (uint64_t)L.n;
             unk <<= 1;
-            SHP(cnt, 3);
             continue;
         }
         if (kind < EU_SH_UNION) {
-            SHP(cnt, 6);
-            const LeafHits lh = leaf_hits<D>(kind, S.params(param), o, d);
-            int n = lh.n;
-            if (sp + 2 > CAP) { cnt.errors++; n = 0; }
-            if (n >= 1) hs.set(sp, lh.t0, i);
-            if (n >= 2) hs.set(sp + 1, lh.t1, i | EU_HIT_SECOND);
-            sp += (uint32_t)n;
-            lens = (lens << 8) | (uint64_t)n;
+            const CsgList L = push_leaf<D>(kind, S.params(param), o, d, hs, sp, i, cnt);
+            lens = (lens << 8) | (uint64_t)L.n;
             unk <<= 1;
-            SHP(cnt, 4);
             continue;
         }
-        SHP(cnt, 6);
         /* composite: children b = ops[i-1] (subtree [fb, i-1]), a = ops[fb-1] (subtree [f, fb-1]) */
         uint32_t kb, fb, pb, cb_;
         S.op(i - 1, kb, fb, pb, cb_);
@@ -739,99 +855,31 @@ EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, cons
         const uint32_t ra = fb - 1, rb = i - 1;
         const uint32_t lb = (uint32_t)(lens & 0xff), la = (uint32_t)((lens >> 8) & 0xff);
         lens >>= 16;
-        const bool unk_b = (unk & 1u) != 0, unk_a = (unk & 2u) != 0;
+        const CsgList B = {lb & 0x7f, (lb & 0x80) != 0, (unk & 1u) != 0}, A = {la & 0x7f, (la & 0x80) != 0, (unk & 2u) != 0};
         unk >>= 2;
-        bool out_unk = false;
-        const uint32_t nb = lb & 0x7f, na = la & 0x7f;
-        const bool rep_a = (la & 0x80) != 0 && na > 0, rep_b = (lb & 0x80) != 0 && nb > 0;
-        const uint32_t b0 = sp - nb, a0 = b0 - na, o0 = sp;
-        uint32_t ia = 0, ib = 0, no = 0;
-        bool out_rep = false;
-        const uint32_t guard_max = 4 * (na + nb) + 8;
-        for (uint32_t guard = 0;; guard++) {
-            const bool sa = ia < na || rep_a, sb = ib < nb || rep_b;
-            if ((!sa && unk_a) || (!sb && unk_b)) { out_unk = true; break; }      /* next() asks both children first (shape.rs:214-215 ...) */
-            if (!sa && !sb) break;
-            if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
-            double ta = R(0.0), tb = R(0.0); uint32_t ca = 0, cb = 0;
-            if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
-            if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
-            const bool both = sa && sb;
-            const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
-            if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
-                if (o0 + no >= CAP) { if (!(i == root && no > 0)) cnt.errors++; break; }  /* capacity (na + nb + 1; at the root only element 0 matters) */
-                hs.set(o0 + no, ta, ca); no++;
-                out_rep = true;
-                break;
-            }
-            /* consuming the repeated tail of a never-ending child stream leaves the iterator state
-             * unchanged: the same decision recurs forever */
-            const bool stuck = take_a ? (ia >= na) : (ib >= nb);
-            const double t = take_a ? ta : tb;
-            uint32_t c = take_a ? ca : cb;
-            double loc[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) loc[k] = o[k] + d[k] * t;
-            const bool ins = take_a ? inside_subtree<D>(S, fb, rb, loc) : inside_subtree<D>(S, fa, ra, loc);
-            if (take_a) ia++; else ib++;
-            bool emit = false, end = false;
-            switch (kind) {
-            case EU_SH_UNION:                                /* shape.rs:212-264 */
-                if (both) emit = !ins; else { if (ins) end = true; else emit = true; }
-                break;
-            case EU_SH_INTERSECTION:                         /* shape.rs:291-340 */
-                if (both) emit = ins; else { if (ins) emit = true; else end = true; }
-                break;
-            case EU_SH_COMPLEMENT:                           /* shape.rs:365-409 */
-                if (take_a) emit = !ins;                      /* only reachable with both present */
-                else { if (ins) { emit = true; c ^= EU_HIT_FLIP; } else if (!both) end = true; }
-                break;
-            default:                                         /* SymmetricDifference, shape.rs:436-496 */
-                emit = true;
-                if (ins) c ^= EU_HIT_FLIP;
-                break;
-            }
-            /* a decision taken on a repeated tail recurs forever with the same outcome (the state did not change): the
-             * element it would emit is the one emitted the step before, so the list is only marked as repeating */
-            if (stuck) { if (emit) out_rep = true; else if (!end) out_unk = true; break; }   /* no output and no end, forever: the reference would spin */
-            if (emit) {
-                if (o0 + no >= CAP) { if (!(i == root && no > 0)) cnt.errors++; break; }   /* capacity (the loader's bound is na + nb) */
-                hs.set(o0 + no, t, c); no++;
-                /* trace_closest asks an entity's stream for element 0 only (universe/mod.rs:114) and the reference's iterators are
-                 * lazy: what the root's merge would produce after its first element is never computed there */
-                if (i == root) break;
-            }
-            if (end) break;
-        }
-        for (uint32_t k = 0; k < no; k++) hs.set(a0 + k, hs.gt(o0 + k), hs.gc(o0 + k));
-        SHP(cnt, 5);
-        sp = a0 + no;
-        lens = (lens << 8) | (uint64_t)(no | (out_rep ? 0x80u : 0u));
-        unk = (unk << 1) | (out_unk ? 1u : 0u);
+        const CsgList L = csg_merge<D>(kind, i == root, hs, sp, A, B, o, d, cnt,
+                                       [&](const real *p) { return inside_subtree<D>(S, fa, ra, p); },
+                                       [&](const real *p) { return inside_subtree<D>(S, fb, rb, p); });
+        lens = (lens << 8) | (uint64_t)(L.n | (L.rep ? 0x80u : 0u));
+        unk = (unk << 1) | (L.unk ? 1u : 0u);
     }
-    const uint32_t n = (uint32_t)(lens & 0x7f);
-    if (n) { first_t = hs.gt(0); first_c = hs.gc(0); }
-    else if (unk & 1u) cnt.errors++;          /* element 0 itself is something the reference never finishes computing */
-    return n;
+    const CsgList top = {(uint32_t)(lens & 0x7f), false, (unk & 1u) != 0};
+    return csg_root_result(top, hs, cnt, first_t, first_c);
 }
 
 template <int D, class HS>
-EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const double *o, const double *d,
-                           HS &hs, LaneCounters &cnt, double &first_t, uint32_t &first_c) {
+EU_DEV uint32_t eval_shape(const EuScene &S, uint32_t first, uint32_t root, const real *o, const real *d,
+                           HS &hs, LaneCounters &cnt, real &first_t, uint32_t &first_c) {
     bool fail = false;
     return eval_shape<D, HS>(S, first, root, o, d, hs, cnt, first_t, first_c, false, fail);
 }
 
-/* normal of the hit described by `code` at parameter t (recomputed from the leaf) */
+/* normal of a hit on a leaf (P: the leaf's own parameters; a chain's leaf counts as a half-space), recomputed from the leaf */
 template <int D>
-EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const double *d, const double *loc, double *n) {
-    uint32_t kind, f, param, count;
-    S.op(code & 0xffffu, kind, f, param, count);
-    const double *P = S.params(param);
-    if (kind >= EU_SH_CHAIN_UNION) { P += ((code >> 16) & 0xffu) * EU_HS_STRIDE(D); kind = EU_SH_HALFSPACE; }
+EU_DEV void leaf_normal(uint32_t kind, const real *P, const real *o, const real *d, const real *loc, real *n) {
     switch (kind) {
     case EU_SH_SPHERE: {                                  /* shape.rs:708-709 */
-        double v[D];
+        real v[D];
 #pragma unroll
         for (int i = 0; i < D; i++) v[i] = loc[i] - P[i];
         vnormalize<D>(v, n);
@@ -846,8 +894,8 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const d
         for (int i = 0; i < D; i++) n[i] = P[D + 2 + i];
         break;
     default: {                                            /* cylinder: axis point of hit 1 serves both hits (shape.rs:999,1017) */
-        const double t0 = leaf_hits<D>(kind, P, o, d).t0;
-        double l1[D], q[D], v[D];
+        const real t0 = leaf_hits<D>(kind, P, o, d).t0;
+        real l1[D], q[D], v[D];
 #pragma unroll
         for (int i = 0; i < D; i++) l1[i] = o[i] + d[i] * t0;
         cyl_axis_point<D>(P, l1, q);
@@ -857,6 +905,16 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const d
         break;
     }
     }
+}
+
+/* normal of the hit described by `code` at parameter t */
+template <int D>
+EU_DEV void hit_normal(const EuScene &S, uint32_t code, const real *o, const real *d, const real *loc, real *n) {
+    uint32_t kind, f, param, count;
+    S.op(code & 0xffffu, kind, f, param, count);
+    const real *P = S.params(param);
+    if (kind >= EU_SH_CHAIN_UNION) { P += ((code >> 16) & 0xffu) * EU_HS_STRIDE(D); kind = EU_SH_HALFSPACE; }
+    leaf_normal<D>(kind, P, o, d, loc, n);
     if (code & EU_HIT_FLIP) {
 #pragma unroll
         for (int i = 0; i < D; i++) n[i] = -n[i];
@@ -864,7 +922,7 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const double *o, const d
 }
 
 /* Universe::material_at (universe/mod.rs:229-251): first entity containing the point */
-template <int D> EU_DEV int material_at(const EuScene &S, const double *p) {
+template <int D> EU_DEV int material_at(const EuScene &S, const real *p) {
     for (uint32_t e = 0; e < S.n_entities; e++) {
         const EuScene::EntityView E = S.entity(e);
         if (inside_subtree<D>(S, E.shape_first, E.shape_root, p)) return (int)e;
@@ -945,7 +1003,7 @@ template <int D> EU_RPN_INLINE eu_f64 eval_rpn(const EuScene &S, uint64_t prog, 
 
 /* Material::enter / exit (material.rs:135-162); the evaluation context is the vector BEFORE the
  * transformation (material.rs:99-111) */
-template <int D> EU_DEV void material_apply(const EuScene &S, uint32_t material, double *dir, bool exit_) {
+template <int D> EU_DEV void material_apply(const EuScene &S, uint32_t material, real *dir, bool exit_) {
     uint64_t m = S.word(S.off_materials + material);
     uint32_t kind = (uint32_t)m & 0xff, ntr = ((uint32_t)m >> 8), first = (uint32_t)(m >> 32);
     if (kind != EU_MAT_LINEAR) return;
@@ -955,22 +1013,22 @@ template <int D> EU_DEV void material_apply(const EuScene &S, uint32_t material,
 #pragma unroll
         for (int i = 0; i < D; i++) ctx[i] = dir[i];
 #pragma unroll
-        for (int i = 0; i < D; i++) dir[i] = (double)eval_rpn<D>(S, S.word(S.off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i), ctx);
+        for (int i = 0; i < D; i++) dir[i] = (real)eval_rpn<D>(S, S.word(S.off_transforms + 8 * tr + (exit_ ? 4 : 0) + (uint32_t)i), ctx);
     }
 }
 
 /* ------------------------------------------------------------------ palette 0.2.1 (UNVERIFIED third-party semantics) */
-EU_DEV Rgba into_premultiplied(Rgba c) { double a = clamp01(c.a); return Rgba{c.r * a, c.g * a, c.b * a, a}; }
+EU_DEV Rgba into_premultiplied(Rgba c) { real a = clamp01(c.a); return Rgba{c.r * a, c.g * a, c.b * a, a}; }
 EU_DEV Rgba from_premultiplied(Rgba p) {
-    double a = clamp01(p.a);
+    real a = clamp01(p.a);
     Rgba c;
     if (is_normal_f64(a)) { c.r = p.r / a; c.g = p.g / a; c.b = p.b / a; }
     else { c.r = R(0.0); c.g = R(0.0); c.b = R(0.0); }
     c.a = a;
     return c;
 }
-__device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, double sa, double da) {
-    const double one = R(1.0), two = R(2.0);
+__device__ __noinline__ real blend_chan(uint32_t fn, real a, real b, real sa, real da) {
+    const real one = R(1.0), two = R(2.0);
     switch (fn) {
     case EU_BL_OVER: return a + b * (one - sa);
     case EU_BL_INSIDE: return a * da;
@@ -997,10 +1055,10 @@ __device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, doubl
         if (a * two <= sa) return two * a * b + a * (one - da) + b * (one - sa);
         return a * (one + da) + b * (one + sa) - two * a * b - sa * da;
     case EU_BL_SOFT_LIGHT: {
-        double m = is_normal_f64(da) ? b / da : R(0.0);
+        real m = is_normal_f64(da) ? b / da : R(0.0);
         if (a * two <= sa) return b * (sa + (two * a - sa) * (one - m)) + a * (one - da) + b * (one - sa);
         if (b * R(4.0) <= da) {
-            double m2 = m * m, m3 = m2 * m;
+            real m2 = m * m, m3 = m2 * m;
             return da * (two * a - sa) * (m3 * R(16.0) - m2 * R(12.0) - m * R(3.0)) + a - a * da + b;
         }
         return da * (two * a - sa) * (sqrt(m) - m) + a - a * da + b;
@@ -1009,7 +1067,7 @@ __device__ __noinline__ double blend_chan(uint32_t fn, double a, double b, doubl
     default: return a + b - two * a * b;
     }
 }
-EU_DEV double blend_alpha(uint32_t fn, double sa, double da) {
+EU_DEV real blend_alpha(uint32_t fn, real sa, real da) {
     switch (fn) {
     case EU_BL_INSIDE: return clamp01(sa * da);
     case EU_BL_OUTSIDE: return clamp01(sa * (R(1.0) - da));
@@ -1021,7 +1079,7 @@ EU_DEV double blend_alpha(uint32_t fn, double sa, double da) {
 }
 EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
     Rgba o;
-    const double one = R(1.0), two = R(2.0), sa = s.a, da = d.a;
+    const real one = R(1.0), two = R(2.0), sa = s.a, da = d.a;
     switch (fn) {      /* the modes the shipped scenes use are expanded in line; the rest go through blend_chan */
     case EU_BL_OVER:
         o.r = s.r + d.r * (one - sa); o.g = s.g + d.g * (one - sa); o.b = s.b + d.b * (one - sa);
@@ -1046,13 +1104,13 @@ EU_DEV Rgba blend_pre(uint32_t fn, Rgba s, Rgba d) {
     return o;
 }
 EU_DEV Rgba blend_rgba(uint32_t fn, Rgba s, Rgba d) { return from_premultiplied(blend_pre(fn, into_premultiplied(s), into_premultiplied(d))); }   /* surface.rs:315-322 */
-EU_DEV Rgba combine_palette_color(Rgba a, Rgba b, double r) {   /* util.rs:265-285 */
+EU_DEV Rgba combine_palette_color(Rgba a, Rgba b, real r) {   /* util.rs:265-285 */
     if (r <= R(0.0)) return b;
     if (r >= R(1.0)) return a;
     return Rgba{a.r * r + b.r * (R(1.0) - r), a.g * r + b.g * (R(1.0) - r), a.b * r + b.b * (R(1.0) - r), a.a * r + b.a * (R(1.0) - r)};
 }
-EU_DEV uint32_t to_u8(double c, LaneCounters &cnt) {
-    double v = clamp01(c) * R(255.0);
+EU_DEV uint32_t to_u8(real c, LaneCounters &cnt) {
+    real v = clamp01(c) * R(255.0);
     if (v != v) { cnt.nan_px++; return 0; }
     return (uint32_t)v;
 }
@@ -1060,19 +1118,19 @@ EU_DEV uint32_t to_pixel4(Rgba c, LaneCounters &cnt) {
     return to_u8(c.r, cnt) | (to_u8(c.g, cnt) << 8) | (to_u8(c.b, cnt) << 16) | (to_u8(c.a, cnt) << 24);
 }
 EU_DEV Rgba new_u8(uint32_t px) {
-    return Rgba{(double)(px & 0xff) / R(255.0), (double)((px >> 8) & 0xff) / R(255.0), (double)((px >> 16) & 0xff) / R(255.0), (double)(px >> 24) / R(255.0)};
+    return Rgba{(real)(px & 0xff) / R(255.0), (real)((px >> 8) & 0xff) / R(255.0), (real)((px >> 16) & 0xff) / R(255.0), (real)(px >> 24) / R(255.0)};
 }
-EU_DEV void hsv_to_rgb(double hue, double saturation, double value, double &r, double &g, double &b) {
-    double deg = hue;
+EU_DEV void hsv_to_rgb(real hue, real saturation, real value, real &r, real &g, real &b) {
+    real deg = hue;
     if (fabs(deg) < R(1.0e9)) {
         while (deg >= R(360.0)) deg = deg - R(360.0);
         while (deg < R(0.0)) deg = deg + R(360.0);
     }
-    double c = value * saturation;
-    double h = deg / R(60.0);
-    double x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
-    double m = value - c;
-    double red, green, blue;
+    real c = value * saturation;
+    real h = deg / R(60.0);
+    real x = c * (R(1.0) - fabs(fmod(h, R(2.0)) - R(1.0)));
+    real m = value - c;
+    real red, green, blue;
     if (h >= R(0.0) && h < R(1.0)) { red = c; green = x; blue = R(0.0); }
     else if (h >= R(1.0) && h < R(2.0)) { red = x; green = c; blue = R(0.0); }
     else if (h >= R(2.0) && h < R(3.0)) { red = R(0.0); green = c; blue = x; }
@@ -1084,31 +1142,31 @@ EU_DEV void hsv_to_rgb(double hue, double saturation, double value, double &r, d
 
 /* ------------------------------------------------------------------ own 4-D gradient noise (documented substitute
  * for noise 0.4.1 Perlin + rand::random() seed, d3/entity/surface.rs:22-58) */
-EU_DEV double pfade(double t) { return t * t * t * (t * (t * R(6.0) - R(15.0)) + R(10.0)); }
-EU_DEV double plerp(double t, double a, double b) { return a + t * (b - a); }
-EU_DEV double pgrad4(int hash, double x, double y, double z, double w) {
+EU_DEV real pfade(real t) { return t * t * t * (t * (t * R(6.0) - R(15.0)) + R(10.0)); }
+EU_DEV real plerp(real t, real a, real b) { return a + t * (b - a); }
+EU_DEV real pgrad4(int hash, real x, real y, real z, real w) {
     int h = hash & 31;
-    double a = (h < 24) ? x : y;
-    double b = (h < 16) ? y : z;
-    double c = (h < 8) ? z : w;
+    real a = (h < 24) ? x : y;
+    real b = (h < 16) ? y : z;
+    real c = (h < 8) ? z : w;
     return ((h & 1) ? -a : a) + ((h & 2) ? -b : b) + ((h & 4) ? -c : c);
 }
-EU_DEV int pcell(double f) { double m = fmod(f, R(256.0)); return (m == m) ? (((int)m) & 255) : 0; }
-__device__ __noinline__ double perlin4(const uint8_t *perm, double x, double y, double z, double w) {
-    double fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
+EU_DEV int pcell(real f) { real m = fmod(f, R(256.0)); return (m == m) ? (((int)m) & 255) : 0; }
+__device__ __noinline__ real perlin4(const uint8_t *perm, real x, real y, real z, real w) {
+    real fx = floor(x), fy = floor(y), fz = floor(z), fw = floor(w);
     int xi = pcell(fx), yi = pcell(fy), zi = pcell(fz), wi = pcell(fw);
-    double xf = x - fx, yf = y - fy, zf = z - fz, wf = w - fw;
-    double u = pfade(xf), v = pfade(yf), s = pfade(zf), q = pfade(wf);
-    double lw[2];
+    real xf = x - fx, yf = y - fy, zf = z - fz, wf = w - fw;
+    real u = pfade(xf), v = pfade(yf), s = pfade(zf), q = pfade(wf);
+    real lw[2];
     for (int dw = 0; dw < 2; dw++) {
-        double lz[2];
+        real lz[2];
         for (int dz = 0; dz < 2; dz++) {
-            double ly[2];
+            real ly[2];
             for (int dy = 0; dy < 2; dy++) {
-                double n[2];
+                real n[2];
                 for (int dx = 0; dx < 2; dx++) {
                     int hsh = perm[perm[perm[perm[xi + dx] + yi + dy] + zi + dz] + wi + dw];
-                    n[dx] = pgrad4(hsh, xf - (double)dx, yf - (double)dy, zf - (double)dz, wf - (double)dw);
+                    n[dx] = pgrad4(hsh, xf - (real)dx, yf - (real)dy, zf - (real)dz, wf - (real)dw);
                 }
                 ly[dy] = plerp(u, n[0], n[1]);
             }
@@ -1120,35 +1178,35 @@ __device__ __noinline__ double perlin4(const uint8_t *perm, double x, double y, 
 }
 
 /* ------------------------------------------------------------------ textures */
-EU_DEV bool cast_u32(double x, uint32_t &out, LaneCounters &cnt) {   /* NumCast: None (panic) when NaN / out of range */
+EU_DEV bool cast_u32(real x, uint32_t &out, LaneCounters &cnt) {   /* NumCast: None (panic) when NaN / out of range */
     if (!(x > -R(1.0) && x < R(4294967296.0))) { cnt.errors++; out = 0; return false; }
     out = (uint32_t)x;
     return true;
 }
 
-/* MappedTextureImpl::get_color (surface.rs:528-534) = texture(uv_sphere(point)) */
-EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point, LaneCounters &cnt) {
-    const EuFlatMapped *M = S.mapped(id);
-    double p[3], pn[3];                                        /* d3/entity/surface.rs:60-68 (uv_derank drops w) */
+/* MappedTextureImpl::get_color (surface.rs:528-534) = texture(uv_sphere(point)); M: the mapped-texture record, texels: the device
+ * address of its RGBA8 texels (patched into the device copy of the scene at upload) */
+EU_DEV Rgba mapped_get_color(const EuFlatMapped *M, uint64_t texels, const real *point, LaneCounters &cnt) {
+    real p[3], pn[3];                                        /* d3/entity/surface.rs:60-68 (uv_derank drops w) */
 #pragma unroll
     for (int i = 0; i < 3; i++) p[i] = point[i] - M->center[i];
     vnormalize<3>(p, pn);
-    double pu = R(0.5) + eu_atan2(pn[1], pn[0]) / (R(2.0) * EU_PI_C);
-    double pv = R(0.5) - eu_asin(pn[2]) / EU_PI_C;
+    real pu = R(0.5) + eu_atan2(pn[1], pn[0]) / (R(2.0) * EU_PI_C);
+    real pv = R(0.5) - eu_asin(pn[2]) / EU_PI_C;
     const uint32_t W = M->w, H = M->h;
     /* texels live in device (global) memory; the address comes out of the scene blob, so say so: a generic pointer would be
      * read with flat loads (vmcnt and lgkmcnt both) */
     typedef const uint32_t __attribute__((address_space(1))) *global_u32_ptr;
-    const global_u32_ptr tex = (global_u32_ptr)(uintptr_t)S.texels(id);
+    const global_u32_ptr tex = (global_u32_ptr)(uintptr_t)texels;
     if (M->tex_kind == EU_TEX_NEAREST) {                       /* surface.rs:434-451 */
-        double x = floor(pu * M->wd), y = floor(pv * M->hd);
+        real x = floor(pu * M->wd), y = floor(pv * M->hd);
         uint32_t xi, yi;
         cast_u32(x, xi, cnt); cast_u32(y, yi, cnt);
         xi = xi % W; yi = yi % H;
         return new_u8(tex[(size_t)yi * W + xi]);
     }
-    double x = pu * M->wd - R(0.5), y = pv * M->hd - R(0.5);        /* surface.rs:453-489 */
-    double ox = x - floor(x), oy = y - floor(y);
+    real x = pu * M->wd - R(0.5), y = pv * M->hd - R(0.5);        /* surface.rs:453-489 */
+    real ox = x - floor(x), oy = y - floor(y);
     uint32_t x0, x1, y0, y1;
     /* the reference casts x and y once per texel (4 texels, surface.rs:462-472); each coordinate
      * serves two texels, so a failed cast counts twice */
@@ -1162,15 +1220,16 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
     if (y1 >= H) { cnt.errors++; y1 = H - 1; }
     uint32_t p0 = tex[(size_t)y0 * W + x0], p1 = tex[(size_t)y0 * W + x1];
     uint32_t p2 = tex[(size_t)y1 * W + x0], p3 = tex[(size_t)y1 * W + x1];
-    double ch[4];
+    real ch[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        double c0 = (double)((p0 >> (8 * k)) & 0xff), c1 = (double)((p1 >> (8 * k)) & 0xff);
-        double c2 = (double)((p2 >> (8 * k)) & 0xff), c3 = (double)((p3 >> (8 * k)) & 0xff);
+        real c0 = (real)((p0 >> (8 * k)) & 0xff), c1 = (real)((p1 >> (8 * k)) & 0xff);
+        real c2 = (real)((p2 >> (8 * k)) & 0xff), c3 = (real)((p3 >> (8 * k)) & 0xff);
         ch[k] = ((c0 * (R(1.0) - ox) + c1 * ox) * (R(1.0) - oy) + (c2 * (R(1.0) - ox) + c3 * ox) * oy) / R(255.0);
     }
     return Rgba{ch[0], ch[1], ch[2], ch[3]};
 }
+EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const real *point, LaneCounters &cnt) { return mapped_get_color(S.mapped(id), S.texels(id), point, cnt); }
 
 /* ------------------------------------------------------------------ surface providers */
 /* TracingContext (shape.rs:111-125) plus a cache of the angles the providers keep asking for.
@@ -1183,64 +1242,64 @@ EU_DEV Rgba mapped_get_color(const EuScene &S, uint32_t id, const double *point,
  *     x_e = dot(direction, normal) / (|direction| * |normal|)
  * and each value is computed at most once per hit, bit-identical to the separate evaluations. */
 template <int D> struct HitCtx {
-    double loc[D], dir[D], normal[D], nc[D];
+    real loc[D], dir[D], normal[D], nc[D];
     bool exiting;
-    double x_e, ang_e;          /* ang_e = angle_between(direction, normal) */
-    double ang_me;              /* acos(-x_e), NaN -> 0; valid when have_me */
+    real x_e, ang_e;          /* ang_e = angle_between(direction, normal) */
+    real ang_me;              /* acos(-x_e), NaN -> 0; valid when have_me */
     bool have_me;
-    double sin_from, to_mult, to_theta;   /* Fresnel / Snell: sin(from_theta); asin(to_mult * sin_from) */
+    real sin_from, to_mult, to_theta;   /* Fresnel / Snell: sin(from_theta); asin(to_mult * sin_from) */
     bool have_sin, have_to;
 
-    EU_DEV void finish(double best_t, const double *o, const double *d) {
+    EU_DEV void finish(real best_t, const real *o, const real *d) {
 #pragma unroll
         for (int k = 0; k < D; k++) { loc[k] = o[k] + d[k] * best_t; dir[k] = d[k]; }
     }
     EU_DEV void classify() {    /* universe/mod.rs:118-125 */
         x_e = vdot<D>(dir, normal) / (vnorm<D>(dir) * vnorm<D>(normal));
-        const double r = eu_acos(x_e);
+        const real r = eu_acos(x_e);
         ang_e = (r != r) ? R(0.0) : r;
         have_me = false; have_sin = false; have_to = false;
         exiting = ang_e < EU_FRAC_PI_2_C;
 #pragma unroll
         for (int k = 0; k < D; k++) nc[k] = exiting ? -normal[k] : normal[k];
     }
-    EU_DEV double angle_neg() {
-        if (!have_me) { const double r = eu_acos(-x_e); ang_me = (r != r) ? R(0.0) : r; have_me = true; }
+    EU_DEV real angle_neg() {
+        if (!have_me) { const real r = eu_acos(-x_e); ang_me = (r != r) ? R(0.0) : r; have_me = true; }
         return ang_me;
     }
-    EU_DEV double angle_dir_nc() { return exiting ? angle_neg() : ang_e; }          /* angle_between(nc, dir) */
-    EU_DEV double angle_dir_minus_nc() { return exiting ? ang_e : angle_neg(); }    /* angle_between(dir, -nc) */
-    EU_DEV double sin_from_theta() {
+    EU_DEV real angle_dir_nc() { return exiting ? angle_neg() : ang_e; }          /* angle_between(nc, dir) */
+    EU_DEV real angle_dir_minus_nc() { return exiting ? ang_e : angle_neg(); }    /* angle_between(dir, -nc) */
+    EU_DEV real sin_from_theta() {
         if (!have_sin) { sin_from = eu_sin(angle_dir_minus_nc()); have_sin = true; }
         return sin_from;
     }
-    EU_DEV double to_theta_for(double mult) {                                        /* asin(mult * sin(from_theta)) */
+    EU_DEV real to_theta_for(real mult) {                                        /* asin(mult * sin(from_theta)) */
         if (have_to && mult == to_mult) return to_theta;
         to_mult = mult; to_theta = eu_asin(mult * sin_from_theta()); have_to = true;
         return to_theta;
     }
 };
 
-template <int D> EU_DEV double reflection_ratio(const EuFlatSurface *F, HitCtx<D> &c) {
+template <int D> EU_DEV real reflection_ratio(const EuFlatSurface *F, HitCtx<D> &c) {
     if (F->ratio_kind == EU_RATIO_UNIFORM) return c.exiting ? R(0.0) : F->ratio_p0;     /* surface.rs:200-211 */
-    const double from_theta = c.angle_dir_minus_nc();                                 /* surface.rs:213-244 */
-    const double from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
-    const double to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
-    const double to_theta = c.to_theta_for(from_index / to_index);
+    const real from_theta = c.angle_dir_minus_nc();                                 /* surface.rs:213-244 */
+    const real from_index = c.exiting ? F->ratio_p0 : F->ratio_p1;
+    const real to_index = c.exiting ? F->ratio_p1 : F->ratio_p0;
+    const real to_theta = c.to_theta_for(from_index / to_index);
     if (to_theta != to_theta) return R(1.0);
-    const double cos_from = eu_cos(from_theta), cos_to = eu_cos(to_theta);
-    double p1s = from_index * cos_from;
-    double p2s = to_index * cos_to;
-    double p1p = from_index * cos_to;
-    double p2p = to_index * cos_from;
-    double rs = (p1s - p2s) / (p1s + p2s); rs = rs * rs;
-    double rp = (p1p - p2p) / (p1p + p2p); rp = rp * rp;
+    const real cos_from = eu_cos(from_theta), cos_to = eu_cos(to_theta);
+    real p1s = from_index * cos_from;
+    real p2s = to_index * cos_to;
+    real p1p = from_index * cos_to;
+    real p2p = to_index * cos_from;
+    real rs = (p1s - p2s) / (p1s + p2s); rs = rs * rs;
+    real rp = (p1p - p2p) / (p1p + p2p); rp = rp * rp;
     return (rs + rp) / (R(1.0) + R(1.0));
 }
 
 /* GeneralRotation::general_rotation for one vector (util.rs:631-666) */
-template <int D> EU_DEV void general_rotation(const double *self, const double *other, double angle, double *vec) {
-    double orig[D][D], res[D][D];
+template <int D> EU_DEV void general_rotation(const real *self, const real *other, real angle, real *vec) {
+    real orig[D][D], res[D][D];
 #pragma unroll
     for (int r = 0; r < D; r++)
 #pragma unroll
@@ -1255,33 +1314,33 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int i = 1; i < D; i++) {
 #pragma unroll
         for (int j = 0; j < i; j++) {
-            double oc[D], rj[D];
+            real oc[D], rj[D];
 #pragma unroll
             for (int r = 0; r < D; r++) { oc[r] = orig[r][i]; rj[r] = res[r][j]; }
-            double dd = vdot<D>(rj, oc);
+            real dd = vdot<D>(rj, oc);
 #pragma unroll
             for (int r = 0; r < D; r++) orig[r][i] = oc[r] - rj[r] * dd;
         }
-        double col[D], ncol[D];
+        real col[D], ncol[D];
 #pragma unroll
         for (int r = 0; r < D; r++) col[r] = orig[r][i];
         vnormalize<D>(col, ncol);
 #pragma unroll
         for (int r = 0; r < D; r++) res[r][i] = ncol[r];
     }
-    double rot[D][D];
+    real rot[D][D];
 #pragma unroll
     for (int r = 0; r < D; r++)
 #pragma unroll
         for (int c = 0; c < D; c++) rot[r][c] = (r == c) ? R(1.0) : R(0.0);
-    double ca = eu_cos(angle), sa = eu_sin(angle);
+    real ca = eu_cos(angle), sa = eu_sin(angle);
     rot[0][0] = ca; rot[0][1] = -sa; rot[1][0] = sa; rot[1][1] = ca;
-    double tmp[D][D], fin[D][D];
+    real tmp[D][D], fin[D][D];
 #pragma unroll
     for (int r = 0; r < D; r++)
 #pragma unroll
         for (int c = 0; c < D; c++) {
-            double acc = R(0.0);
+            real acc = R(0.0);
 #pragma unroll
             for (int k = 0; k < D; k++) acc = acc + rot[r][k] * res[c][k];
             tmp[r][c] = acc;
@@ -1290,15 +1349,15 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int r = 0; r < D; r++)
 #pragma unroll
         for (int c = 0; c < D; c++) {
-            double acc = R(0.0);
+            real acc = R(0.0);
 #pragma unroll
             for (int k = 0; k < D; k++) acc = acc + res[r][k] * tmp[k][c];
             fin[r][c] = acc;
         }
-    double out[D];
+    real out[D];
 #pragma unroll
     for (int r = 0; r < D; r++) {
-        double acc = R(0.0);
+        real acc = R(0.0);
 #pragma unroll
         for (int k = 0; k < D; k++) acc = acc + fin[r][k] * vec[k];
         out[r] = acc;
@@ -1307,23 +1366,58 @@ template <int D> EU_DEV void general_rotation(const double *self, const double *
     for (int r = 0; r < D; r++) vec[r] = out[r];
 }
 
-template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, HitCtx<D> &c, double *out) {
+template <int D> EU_DEV void threshold_direction(const EuFlatSurface *F, HitCtx<D> &c, real *out) {
 #pragma unroll
     for (int i = 0; i < D; i++) out[i] = c.dir[i];
     if (F->thr_kind == EU_THR_IDENTITY) return;                     /* surface.rs:258-266 */
-    double normal[D];                                               /* surface.rs:268-288 */
+    real normal[D];                                               /* surface.rs:268-288 */
 #pragma unroll
     for (int i = 0; i < D; i++) normal[i] = -c.nc[i];
-    const double from_theta = c.angle_dir_minus_nc();
-    const double modifier = c.exiting ? F->thr_p0 : F->thr_p0_inv;
-    const double to_theta = c.to_theta_for(modifier);
-    const double angle_delta = to_theta - from_theta;
+    const real from_theta = c.angle_dir_minus_nc();
+    const real modifier = c.exiting ? F->thr_p0 : F->thr_p0_inv;
+    const real to_theta = c.to_theta_for(modifier);
+    const real angle_delta = to_theta - from_theta;
     general_rotation<D>(normal, c.dir, angle_delta, out);
+}
+
+/* the surface-colour providers, one function per kind (C: the provider's record).  Shared by the interpreter's program loop
+ * (surface_color) and the scene-specialised kernels, which call them in post-order with the records as constants. */
+EU_DEV Rgba col_uniform(const EuFlatColorOp *C) { return Rgba{(real)C->c0[0], (real)C->c0[1], (real)C->c0[2], (real)C->c0[3]}; }       /* surface.rs:424-429 */
+EU_DEV Rgba col_blend(const EuFlatColorOp *C, const Rgba src, const Rgba dst) {                                                         /* surface.rs:295-322 */
+    return (C->fn == EU_BL_RATIO) ? combine_palette_color(src, dst, C->v[0]) : blend_rgba(C->fn, src, dst);
+}
+template <int D> EU_DEV Rgba col_illum_global(const EuFlatColorOp *C, HitCtx<D> &c) {                                                   /* surface.rs:410-422 */
+    real original_angle = c.angle_dir_nc();
+    real angle = EU_PI_C - original_angle;
+    real ratio = angle / EU_FRAC_PI_2_C;
+    return combine_palette_color(Rgba{(real)C->c1[0], (real)C->c1[1], (real)C->c1[2], (real)C->c1[3]}, Rgba{(real)C->c0[0], (real)C->c0[1], (real)C->c0[2], (real)C->c0[3]}, ratio);
+}
+template <int D> EU_DEV Rgba col_illum_dir(const EuFlatColorOp *C, HitCtx<D> &c) {                                                      /* surface.rs:392-408 */
+    real normal[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) normal[k] = c.normal[k];
+    if (c.ang_e > EU_FRAC_PI_2_C) {
+#pragma unroll
+        for (int k = 0; k < D; k++) normal[k] = -normal[k];
+    }
+    real nl[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) nl[k] = C->v[k];            /* = -light_direction, negated at load */
+    real angle = angle_between<D>(normal, nl);
+    real ratio = R(1.0) - angle / EU_PI_C;
+    return combine_palette_color(Rgba{(real)C->c1[0], (real)C->c1[1], (real)C->c1[2], (real)C->c1[3]}, Rgba{(real)C->c0[0], (real)C->c0[1], (real)C->c0[2], (real)C->c0[3]}, ratio);
+}
+template <int D> EU_DEV Rgba col_perlin(const EuFlatColorOp *C, const uint8_t *perm, HitCtx<D> &c, real time_s) {                       /* d3/entity/surface.rs:22-40 */
+    real value = perlin4(perm, c.loc[0] / C->v[0], c.loc[1] / C->v[0], c.loc[D > 2 ? 2 : 0] / C->v[0], time_s * C->v[1]);
+    Rgba v;
+    hsv_to_rgb(value * R(360.0), R(1.0), R(1.0), v.r, v.g, v.b);
+    v.a = R(1.0);
+    return v;
 }
 
 /* the surface-colour provider tree, evaluated as a post-order program on a small stack */
 template <int D>
-EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c, double time_s, LaneCounters &cnt, double *cst, uint32_t stride) {
+EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c, real time_s, LaneCounters &cnt, real *cst, uint32_t stride) {
     /* stack of at most 4 colours in LDS, lane-interleaved (entry k, channel j of this lane at cst[(4 k + j) * stride]):
      * a run-time indexed private array would be scratch memory, and every scratch access waits on vmcnt */
     int sp = 0;
@@ -1331,51 +1425,85 @@ EU_DEV Rgba surface_color(const EuScene &S, const EuFlatSurface *F, HitCtx<D> &c
         const EuFlatColorOp *C = S.color_op(i);
         Rgba v;
         switch (C->kind) {
-        case EU_COL_UNIFORM: v = Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}; break;       /* surface.rs:424-429 */
-        case EU_COL_BLEND: {                                                                  /* surface.rs:295-322 */
-            const double *pd = cst + (uint32_t)(((sp - 1) & 3) * 4) * stride, *ps = cst + (uint32_t)(((sp - 2) & 3) * 4) * stride;
+        case EU_COL_UNIFORM: v = col_uniform(C); break;
+        case EU_COL_BLEND: {
+            const real *pd = cst + (uint32_t)(((sp - 1) & 3) * 4) * stride, *ps = cst + (uint32_t)(((sp - 2) & 3) * 4) * stride;
             const Rgba dst = {pd[0], pd[stride], pd[2 * stride], pd[3 * stride]}, src = {ps[0], ps[stride], ps[2 * stride], ps[3 * stride]};
             sp -= 2;
-            v = (C->fn == EU_BL_RATIO) ? combine_palette_color(src, dst, C->v[0]) : blend_rgba(C->fn, src, dst);
+            v = col_blend(C, src, dst);
             break;
         }
-        case EU_COL_ILLUM_GLOBAL: {                                                           /* surface.rs:410-422 */
-            double original_angle = c.angle_dir_nc();
-            double angle = EU_PI_C - original_angle;
-            double ratio = angle / EU_FRAC_PI_2_C;
-            v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
-            break;
-        }
-        case EU_COL_ILLUM_DIR: {                                                              /* surface.rs:392-408 */
-            double normal[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) normal[k] = c.normal[k];
-            if (c.ang_e > EU_FRAC_PI_2_C) {
-#pragma unroll
-                for (int k = 0; k < D; k++) normal[k] = -normal[k];
-            }
-            double nl[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) nl[k] = C->v[k];            /* = -light_direction, negated at load */
-            double angle = angle_between<D>(normal, nl);
-            double ratio = R(1.0) - angle / EU_PI_C;
-            v = combine_palette_color(Rgba{C->c1[0], C->c1[1], C->c1[2], C->c1[3]}, Rgba{C->c0[0], C->c0[1], C->c0[2], C->c0[3]}, ratio);
-            break;
-        }
-        case EU_COL_PERLIN: {                                                                 /* d3/entity/surface.rs:22-40 */
-            double value = perlin4(S.perlin(C->aux), c.loc[0] / C->v[0], c.loc[1] / C->v[0], c.loc[D > 2 ? 2 : 0] / C->v[0], time_s * C->v[1]);
-            hsv_to_rgb(value * R(360.0), R(1.0), R(1.0), v.r, v.g, v.b);
-            v.a = R(1.0);
-            break;
-        }
+        case EU_COL_ILLUM_GLOBAL: v = col_illum_global<D>(C, c); break;
+        case EU_COL_ILLUM_DIR: v = col_illum_dir<D>(C, c); break;
+        case EU_COL_PERLIN: v = col_perlin<D>(C, S.perlin(C->aux), c, time_s); break;
         default: v = mapped_get_color(S, C->aux, c.loc, cnt); break;                          /* surface.rs:536-542 */
         }
         if (i == F->color_root) return v;        /* the root's value is the result (post-order: the stack is empty below it) */
-        double *pw = cst + (uint32_t)((sp & 3) * 4) * stride;
+        real *pw = cst + (uint32_t)((sp & 3) * 4) * stride;
         pw[0] = v.r; pw[stride] = v.g; pw[2 * stride] = v.b; pw[3 * stride] = v.a;
         sp++;
     }
     return Rgba{R(0.0), R(0.0), R(0.0), R(0.0)};     /* not reached: color_first <= color_root */
 }
+
+/* ------------------------------------------------------------------ what get_color asks of the hit surface
+ * ComposableSurface::get_color up to its recursive calls (surface.rs:62-162): the clamped reflection ratio, then -- unless the
+ * surface is a perfect mirror -- the surface colour, its u8 quantisation (get_intersection_color tests the QUANTISED alpha,
+ * surface.rs:72-76), and for a translucent colour the transmission direction.  colour(): the surface-colour provider tree. */
+template <int D> struct SurfaceEval {
+    real ratio;             /* clamped to [0, 1] (surface.rs:145-147) */
+    bool have_color;        /* ratio < 1: sc / spx are valid */
+    Rgba sc; uint32_t spx;
+    bool translucent;       /* quantised alpha != 255: thr[] is the transmission direction before the materials' transformations */
+    real thr[D];
+};
+template <int D, class ColorFn>
+EU_DEV void surface_eval(const EuFlatSurface *F, HitCtx<D> &c, LaneCounters &cnt, SurfaceEval<D> &E, ColorFn color) {
+    real ratio = reflection_ratio<D>(F, c);
+    E.ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));                               /* surface.rs:145-147 */
+    E.have_color = false; E.translucent = false; E.spx = 0;
+    E.sc = Rgba{R(0.0), R(0.0), R(0.0), R(0.0)};
+    if (!(E.ratio >= R(1.0))) {                                                       /* get_intersection_color, surface.rs:62-117 */
+        E.sc = color();
+        E.have_color = true;
+        E.spx = to_pixel4(E.sc, cnt);
+        if ((E.spx >> 24) != 255u) { threshold_direction<D>(F, c, E.thr); E.translucent = true; }
+    }
+}
+
+/* ------------------------------------------------------------------ the scene as the trace kernels see it
+ * The kernels of trace_wavefront.h are templates over a scene policy P.  EuInterp<D> below is the interpreter: every question is
+ * answered by walking the flat scene (shape programs, colour programs, RPN code).  A scene-specialised policy (generated and
+ * compiled when the renderer is created, jit.cpp) answers the same questions with straight-line code for ONE scene; both call the
+ * arithmetic of this header, so they cannot differ in a single bit. */
+template <int D> struct EuInterp {
+    static constexpr bool kInterpreter = true;
+    /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
+    template <class HS>
+    static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, bool use_box, bool &fail,
+                                     bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {
+        for (uint32_t e = 0; e < S.n_entities; e++) {
+            const EuScene::EntityView E = S.entity(e);
+            if (E.surface < 0) continue;
+            if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
+            real t = R(0.0); uint32_t code = 0;
+            const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, hs, cnt, t, code, use_box, fail);
+            if (n == 0) continue;
+            if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
+        }
+    }
+    static EU_DEV void hit_normal(const EuScene &S, uint32_t ent, uint32_t code, const real *o, const real *d, const real *loc, real *n) {
+        ::hit_normal<D>(S, code, o, d, loc, n);
+    }
+    static EU_DEV void surface(const EuScene &S, uint32_t ent, HitCtx<D> &c, real time_s, LaneCounters &cnt, real *cst, uint32_t stride, SurfaceEval<D> &E) {
+        const EuScene::EntityView HE = S.entity(ent);
+        const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
+        surface_eval<D>(F, c, cnt, E, [&]() { return surface_color<D>(S, F, c, time_s, cnt, cst, stride); });
+    }
+    static EU_DEV int material_at(const EuScene &S, const real *p) { return ::material_at<D>(S, p); }
+    /* Material::enter / exit of the material of entity `ent` */
+    static EU_DEV void material_apply(const EuScene &S, uint32_t ent, real *dir, bool exit_) { ::material_apply<D>(S, S.entity(ent).material, dir, exit_); }
+    static EU_DEV Rgba background(const EuScene &S, const real *point, LaneCounters &cnt) { return mapped_get_color(S, S.background, point, cnt); }
+};
 
 #endif

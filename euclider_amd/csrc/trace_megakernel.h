@@ -6,8 +6,6 @@
 #ifndef EU_TRACE_MEGAKERNEL_H
 #define EU_TRACE_MEGAKERNEL_H
 
-#include <type_traits>
-
 #include "trace_device.h"
 
 #define EU_BLOCK 256
@@ -40,10 +38,10 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
     EuScene S;
     S.init(base);
 
-    typename std::conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
+    typename eu_conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
     if constexpr (HSCAP == 0) {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double *hs_t = (double *)(lds_dyn + lds_words);
+        real *hs_t = (real *)(lds_dyn + lds_words);
         uint32_t *hs_c = (uint32_t *)(hs_t + (EU_BLOCK / 64) * hs_cap * 64);
         HS.t = hs_t + wave * hs_cap * 64 + lane;
         HS.c = hs_c + wave * hs_cap * 64 + lane;
@@ -61,11 +59,11 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
     /* lane state */
     bool active = false;
     uint32_t px_x = 0, px_y = 0, out_idx = 0;
-    double o[D], d[D];
+    real o[D], d[D];
     int ent = 0;
     uint32_t depth = 0, fsp = 0;
     bool primary = false;
-    double first_hit = -R(1.0);
+    real first_hit = -R(1.0);
 
     for (;;) {
         /* ---- refill: idle lanes pull the next pixel (wave-aggregated atomic) ---- */
@@ -111,13 +109,13 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
             }
             /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
             const int sw = (int)fr.width, sh = (int)fr.height;
-            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / R(2.0);
-            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / R(2.0);
-            double dl[D];
+            const real rel_x = (real)((int)px_x - sw / 2) + (real)(1 - sw % 2) / R(2.0);
+            const real rel_y = (real)((int)px_y - sh / 2) + (real)(1 - sh % 2) / R(2.0);
+            real dl[D];
 #pragma unroll
             for (int i = 0; i < D; i++) {
-                const double center = cam.location[i] + cam.forward[i] * cam.dist;
-                const double p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
+                const real center = cam.location[i] + cam.forward[i] * cam.dist;
+                const real p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
                 dl[i] = p - cam.location[i];
                 o[i] = cam.location[i];
             }
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
 #endif
         {
             bool have = false;
-            double best_t = R(0.0);
+            real best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0;
             if (depth > 0) {
                 cnt.rays++;
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 for (uint32_t e = 0; e < S.n_entities; e++) {
                     const EuScene::EntityView E = S.entity(e);
                     if (E.surface < 0) continue;
-                    double t = R(0.0); uint32_t code = 0;
+                    real t = R(0.0); uint32_t code = 0;
                     const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                     if (n == 0) continue;
                     if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
@@ -175,16 +173,16 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                 c.classify();
                 const EuScene::EntityView HE = S.entity(best_ent);
                 const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
-                double ratio = reflection_ratio<D>(F, c);
+                real ratio = reflection_ratio<D>(F, c);
                 ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));
 
                 bool have_inter = false, need_trans = false;
                 Rgba inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
                 uint32_t spx = 0;
-                double t_o[D], t_d[D];
+                real t_o[D], t_d[D];
                 int dest = -1;
                 if (!(ratio >= R(1.0))) {                                              /* get_intersection_color */
-                    double cst_priv[16];
+                    real cst_priv[16];
                     const Rgba sc = surface_color<D>(S, F, c, fr.time_s, cnt, cst_priv, 1u);
                     spx = to_pixel4(sc, cnt);
                     if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
@@ -201,9 +199,9 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
                     }
                 }
                 const bool need_refl = !(ratio <= R(0.0));                              /* get_reflection_color */
-                double r_o[D], r_d[D];
+                real r_o[D], r_d[D];
                 if (need_refl) {
-                    const double dn = vdot<D>(c.dir, c.nc);
+                    const real dn = vdot<D>(c.dir, c.nc);
 #pragma unroll
                     for (int i = 0; i < D; i++) {
                         r_d[i] = c.nc[i] * -R(2.0) * dn + c.dir[i];                     /* surface.rs:246-256 */
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
             } else {
                 /* background().get_color(&direction.to_point()) (universe/mod.rs:183) */
                 cnt.bg++;
-                double pt[D];
+                real pt[D];
 #pragma unroll
                 for (int i = 0; i < D; i++) pt[i] = R(0.0) + d[i];
                 ret = mapped_get_color(S, S.background, pt, cnt);

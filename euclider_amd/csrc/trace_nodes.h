@@ -1,6 +1,6 @@
 /*
- * trace_nodes.h -- the tree nodes of the trace recursion and the delivery of finished colours, shared by the wavefront
- * pipeline (trace_wavefront.h) and the stream kernel (trace_stream.h).
+ * trace_nodes.h -- the tree nodes of the trace recursion and the delivery of finished colours, used by the wavefront
+ * pipeline (trace_wavefront.h).
  *
  * A ray whose colour needs its children's colours (ComposableSurface::get_color: over / combine,
  * /root/reference/src/universe/entity/surface.rs:104-114,159-161) leaves one 64-byte NODE.  A finished colour is DELIVERED to
@@ -19,8 +19,8 @@ enum { TS_NONE = 0, TS_OVER = 2, TS_COMBINE_TRANS = 3, TS_COMBINE_INTER = 4 };
 enum { TS_MODE_F64 = 0, TS_MODE_U8 = 1, TS_MODE_INTER = 2, TS_MODE_ROOT = 3 };
 
 struct EuTsNode {               /* 64 bytes */
-    double c1[4];               /* slot 1: the reflection's colour (COMBINE_TRANS) | the surface colour, replaced by the combined result when the reflection arrives (COMBINE_INTER) */
-    double ratio;
+    real c1[4];               /* slot 1: the reflection's colour (COMBINE_TRANS) | the surface colour, replaced by the combined result when the reflection arrives (COMBINE_INTER) */
+    real ratio;
     uint32_t c0px;              /* slot 0: the transmitted colour, quantised by whoever delivers it */
     uint32_t spx;               /* the surface colour, quantised */
     uint32_t parent;            /* node id, or the pixel's index in the frame buffer */
@@ -28,13 +28,13 @@ struct EuTsNode {               /* 64 bytes */
 };
 
 
-template <int D> EU_DEV Rgba ts_background(const EuScene &S, const double *d, LaneCounters &cnt) {
+template <int D, class P> EU_DEV Rgba ts_background(const EuScene &S, const real *d, LaneCounters &cnt) {
     /* background().get_color(&direction.to_point()) (universe/mod.rs:183) */
     cnt.bg++;
-    double pt[D];
+    real pt[D];
 #pragma unroll
     for (int i = 0; i < D; i++) pt[i] = R(0.0) + d[i];
-    return mapped_get_color(S, S.background, pt, cnt);
+    return P::background(S, pt, cnt);
 }
 
 /* hand a finished colour to whoever waits for it */

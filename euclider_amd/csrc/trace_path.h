@@ -15,23 +15,23 @@
 #define EU_PATH_MAX_STEPS 4096u      /* surface crossings per call; beyond it the call fails (the reference would overflow its stack) */
 
 struct EuPathResult {
-    double location[4], direction[4];
+    real location[4], direction[4];
     int32_t found;                   /* 1 = Some, 0 = None (no material at the start), -1 = step cap */
     uint32_t steps;                  /* surfaces crossed */
 };
 
 template <int D>
-__global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__restrict__ scene_g, const double *__restrict__ in /* location[D], direction[D], distance */,
+__global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__restrict__ scene_g, const real *__restrict__ in /* location[D], direction[D], distance */,
                                                            EuPathResult *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     EuScene S;
     S.init(scene_g);
     HitStackPriv<96> HS;
     LaneCounters cnt = {0, 0, 0, 0};
-    double o[D], d[D];
+    real o[D], d[D];
 #pragma unroll
     for (int k = 0; k < D; k++) { o[k] = in[k]; d[k] = in[D + k]; }
-    double distance = in[2 * D];
+    real distance = in[2 * D];
     EuPathResult res;
     for (int k = 0; k < 4; k++) { res.location[k] = R(0.0); res.direction[k] = R(0.0); }
     res.found = 0; res.steps = 0;
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
         for (uint32_t step = 0; step <= EU_PATH_MAX_STEPS; step++) {
             /* trace_closest over surfaced entities (universe/mod.rs:194-196) */
             bool have = false;
-            double best_t = R(0.0);
+            real best_t = R(0.0);
             uint32_t best_code = 0, best_ent = 0;
             for (uint32_t e = 0; e < S.n_entities; e++) {
                 const EuScene::EntityView E = S.entity(e);
                 if (E.surface < 0) continue;
                 if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
-                double t = R(0.0); uint32_t code = 0;
+                real t = R(0.0); uint32_t code = 0;
                 const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, cnt, t, code);
                 if (n == 0) continue;
                 if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void eu_trace_path_kernel(const uint64_t *__res
                 c.finish(best_t, o, d);
                 hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
                 c.classify();
-                double no[D];
+                real no[D];
 #pragma unroll
                 for (int k = 0; k < D; k++) no[k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0);
                 const int dest = c.exiting ? material_at<D>(S, no) : (int)best_ent;   /* surface.rs:177-185 */

@@ -5,19 +5,23 @@
  * (/root/reference/src/universe/mod.rs:149-184, universe/entity/surface.rs:62-162).  Here the recursion
  * tree of the whole frame is processed one GENERATION (= recursion depth) at a time:
  *
- *   gen kernel            one thread per pixel: camera ray, material_at, Material::enter -> ray queue 0
  *   for g = 0 .. max_depth-1
- *     intersect kernel    one thread per queued ray: Universe::trace_closest -> (t, hit code, entity)
+ *     intersect kernel    one thread per ray of generation g: Universe::trace_closest -> (t, hit code, entity).
+ *                         Generation 0 has no queue: its rays are computed from the pixel index (camera ray,
+ *                         material_at, Material::enter) here and again in the shade kernel
  *     shade kernel        one thread per ray: ComposableSurface::get_color up to the recursive calls:
- *                         a finished colour is DELIVERED to the parent's child slot; otherwise a tree
+ *                         a finished colour is DELIVERED to the parent's child slot (a primary ray's colour:
+ *                         fg.over(white), to_pixel -> the RGBA8 pixel, universe/mod.rs:263-269,342); otherwise a tree
  *                         node {kind, quantised surface pixel, ratio} is created and 1-2 child rays are
- *                         appended to queue g+1 (wave-aggregated atomics)
+ *                         appended to queue g+1 (wave-aggregated LDS counter)
  *   for g = max_depth-1 .. 0
  *     resolve kernel      one thread per node of generation g: over / combine of the delivered child
  *                         colours (surface.rs:104-114,159-161) -> delivered to its own parent
- *   final kernel          per pixel: fg.over(white), to_pixel (universe/mod.rs:263-269,342) -> RGBA8
  *
- * Everything a ray needs between kernels lives in HBM as struct-of-arrays queues (coalesced), sized
+ * The kernels are templates over a scene policy (trace_device.h, EuInterp<D>): the ahead-of-time library instantiates them
+ * with the interpreter of the flat scene; jit.cpp instantiates the same bodies with straight-line code generated for one scene.
+ *
+ * Everything a ray needs between kernels lives in HBM as queues of records (coalesced), sized
  * for the 288 GB part.  A queue is cut into one SEGMENT per producer workgroup: a workgroup appends
  * its children to its own segment through an LDS counter (no global atomics: a single hot counter
  * saturates at ~88 appends/us on this chip and was the first bottleneck), publishes the segment
@@ -29,8 +33,6 @@
  */
 #ifndef EU_TRACE_WAVEFRONT_H
 #define EU_TRACE_WAVEFRONT_H
-
-#include <type_traits>
 
 #include "trace_device.h"
 #include "trace_nodes.h"
@@ -50,15 +52,10 @@
 #define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
 #endif
 
-/* Diagnostic build only (-DEU_PROFILE_PHASES): s_memtime shares of the shade kernel's sections go to
- * EuDevCounters::phase[]; never to an output.  WF_STAMP(k) closes section k-1 and opens section k. */
-#if defined(EU_PROFILE_SHADE_WAVE)      /* wave-level shares of the shade kernel (LDS rows, first active lane: trace_device.h SHP): STAMP(k) closes section k-1
-                                         * (STAMP(0): what lies between two batches -> 15), SUB(k) closes sub-section k; sections do not overlap */
+#if defined(EU_PROFILE_SHADE_WAVE)      /* diagnostic build: wave-level shares of the shade kernel (LDS rows, first active lane: trace_device.h SHP): STAMP(k) closes
+                                         * section k-1 (STAMP(0): what lies between two batches -> 15), SUB(k) closes sub-section k; sections do not overlap */
 #define WF_STAMP(k) SHP(cnt, (k) > 0 ? (k) - 1 : 15)
 #define WF_SUB(k) SHP(cnt, (k))
-#elif defined(EU_PROFILE_PHASES)
-#define WF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[(k) - 1] += now_ - last_; last_ = now_; last2_ = now_; } while (0)
-#define WF_SUB(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last2_; last2_ = now_; } while (0)
 #else
 #define WF_STAMP(k) do { } while (0)
 #define WF_SUB(k) do { } while (0)
@@ -69,16 +66,16 @@
  * stream per component: 6 + 2 + 3 streams for D = 3) every vector memory instruction of a ray batch went to a different page, 1.5 MB
  * further on than in the batch before, and ISSUING the six component loads took a wave 16 K cycles per batch (`-DEU_PROFILE_SHAPE`: 41 %
  * of the generation-0 intersect kernel; with the same bytes from consecutive words: 11 %). */
-template <int D> struct alignas(2 * sizeof(double)) EuWfRay { double o[D], d[D]; };
+template <int D> struct alignas(2 * sizeof(real)) EuWfRay { real o[D], d[D]; };
 struct alignas(16) EuWfHit {
-    double t; uint32_t code, ent;      /* ent 0xffffffff: nothing hit */
+    real t; uint32_t code, ent;      /* ent 0xffffffff: nothing hit */
 #if EU_REAL_BITS == 32
     uint32_t pad;
 #endif
 };
 static_assert(sizeof(EuWfHit) == 16, "one 16-byte store per ray");
 struct EuWfBuffers {
-    double *ray[2];             /* [ray_cap] EuWfRay<D>: origin then direction; ping-pong by generation */
+    real *ray[2];             /* [ray_cap] EuWfRay<D>: origin then direction; ping-pong by generation */
     uint2 *ray_pa[2];           /* x: node id that receives this ray's colour; y: entity the ray travels in (bits 0..15) | delivery slot / mode (bits 16..18) */
     EuWfHit *hit;               /* per ray of the current generation */
     /* tree nodes (trace_nodes.h): one id per traced ray in queue order, only the slots of rays that need one are touched */
@@ -170,130 +167,88 @@ EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_
 /* ------------------------------------------------------------------ queue helpers */
 struct WfRay { uint32_t q; };
 
-template <int D> EU_DEV void wf_store_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, const double *o, const double *d, uint32_t parent, uint32_t aux) {
+template <int D> EU_DEV void wf_store_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, const real *o, const real *d, uint32_t parent, uint32_t aux) {
     EuWfRay<D> r;
 #pragma unroll
     for (int k = 0; k < D; k++) { r.o[k] = o[k]; r.d[k] = d[k]; }
     ((EuWfRay<D> *)B.ray[buf])[q] = r;
     B.ray_pa[buf][q] = make_uint2(parent, aux);
 }
-template <int D> EU_DEV void wf_load_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, double *o, double *d) {
+template <int D> EU_DEV void wf_load_ray(const EuWfBuffers &B, uint32_t buf, uint32_t q, real *o, real *d) {
     const EuWfRay<D> r = ((const EuWfRay<D> *)B.ray[buf])[q];
 #pragma unroll
     for (int k = 0; k < D; k++) { o[k] = r.o[k]; d[k] = r.d[k]; }
 }
 
-/* ------------------------------------------------------------------ primary rays */
-template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_gen_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,
-                                                                EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba,
-                                                                eu_f64 *__restrict__ hit_t, eu_f64 *__restrict__ point_rgb) {
-    extern __shared__ uint64_t lds_dyn[];
-    __shared__ uint32_t seg_fill;
-    if (threadIdx.x == 0) seg_fill = 0;
-    __syncthreads();      /* the other waves' first append must not overtake the store above */
-    EuScene S;
-    S.init(scene_g);
-    LaneCounters cnt = {0, 0, 0, 0};
-    const unsigned long long total_items = (unsigned long long)fr.n_tiles * 64ull;
-    const uint32_t rows = fr.local_rows;
-    const uint32_t seg_base = blockIdx.x * B.seg_cap;
-    /* every workgroup takes an equal, contiguous share of the pixel tiles (whole 64-pixel tiles), so that
-     * all queue segments fill evenly; whole iterations for every lane (the block-wide append sees all waves) */
-    unsigned long long chunk = (total_items + gridDim.x - 1) / gridDim.x;
-    chunk = (chunk + 63ull) & ~63ull;
-    const unsigned long long chunk_begin = (unsigned long long)blockIdx.x * chunk;
-    const unsigned long long iters = (chunk + blockDim.x - 1) / blockDim.x;
-    /* every camera ray starts at the camera (get_ray_point, d3/entity/camera.rs:147-153): material_at(origin) is one value per frame */
-    const int cam_ent = material_at<D>(S, cam.location);
-    for (unsigned long long it = 0; it < iters; it++) {
-        const unsigned long long local = it * blockDim.x + threadIdx.x;
-        const unsigned long long item = local < chunk ? chunk_begin + local : total_items;
-        bool have_ray = false;
-        double o[D], d[D];
-        uint32_t out_idx = 0, ent_u = 0;
-        do {
-            if (item >= total_items) break;
-            uint32_t px_x, px_y, ry;
-            if (fr.single_pixel) {      /* Environment::trace_screen_point: exactly one item */
-                if (item != 0) break;
-                px_x = fr.single_x; px_y = fr.single_y; ry = 0; out_idx = 0;
-            } else {
-                const uint32_t tile = (uint32_t)(item >> 6), within = (uint32_t)(item & 63);   /* 8x8 pixel tiles: coherent waves */
-                px_x = (tile % fr.tiles_x) * 8 + (within & 7);
-                ry = fr.band_row0 + (tile / fr.tiles_x) * 8 + (within >> 3);
-                if (px_x >= fr.width || ry >= rows || ry >= fr.band_row0 + fr.band_rows) break;
-                out_idx = ry * fr.width + px_x;
-                if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
-                    const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
-                    px_y = fr.row_begin + gstrip * 8 + (ry & 7);
-                    if (px_y >= fr.row_end) {   /* padding rows of the last strip: defined contents */
-                        rgba[out_idx] = 0u;
-                        if (hit_t) hit_t[out_idx] = -R(1.0);
-                        break;
-                    }
-                } else px_y = fr.row_begin + ry;
-            }
-            if (hit_t) hit_t[out_idx] = -R(1.0);
-            /* Environment::render's cross-hair (universe/mod.rs:321-333) */
-            const uint32_t hw = fr.width / 2, hh = fr.height / 2;
-            if (fr.debug_crosshair && ((px_x == hw && (px_y == hh - 1 || px_y == hh + 1)) || (px_y == hh && (px_x == hw - 1 || px_x == hw + 1)))) {
-                rgba[out_idx] = 0xff0000ffu;
-                if (point_rgb) { point_rgb[0] = R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = R(0.0); }
-                break;
-            }
-            /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
-            const int sw = (int)fr.width, sh = (int)fr.height;
-            const double rel_x = (double)((int)px_x - sw / 2) + (double)(1 - sw % 2) / R(2.0);
-            const double rel_y = (double)((int)px_y - sh / 2) + (double)(1 - sh % 2) / R(2.0);
-            double dl[D];
-#pragma unroll
-            for (int i = 0; i < D; i++) {
-                const double center = cam.location[i] + cam.forward[i] * cam.dist;
-                const double p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
-                dl[i] = p - cam.location[i];
-                o[i] = cam.location[i];
-            }
-            vnormalize<D>(dl, d);
-            /* trace_unknown (universe/mod.rs:253-271) */
-            const int ent = cam_ent;
-            if (ent < 0) {   /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
-                const bool black = (((int)px_x / 8 + (int)px_y / 8) % 2) == 0;
-                rgba[out_idx] = black ? 0xff000000u : 0xffff00ffu;
-                if (point_rgb) { point_rgb[0] = black ? R(0.0) : R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = black ? R(0.0) : R(1.0); }
-                break;
-            }
-            material_apply<D>(S, S.entity((uint32_t)ent).material, d, false);
-            if (cam.max_depth == 0) {   /* trace() with depth 0 goes straight to the background */
-                ts_deliver(B.nodes, out_idx, TS_MODE_ROOT << 1, ts_background<D>(S, d, cnt), cnt, rgba, point_rgb);
-                break;
-            }
-            ent_u = (uint32_t)ent;
-            have_ray = true;
-        } while (false);
-        uint32_t second;
-        const uint32_t pos = wf_append_local(&seg_fill, have_ray ? 1u : 0u, second);
-        if (have_ray) {
-            if (pos >= B.seg_cap) cnt.errors++, atomicAdd(&counters->overflow, 1ull);
-            else wf_store_ray<D>(B, 0, seg_base + pos, o, d, out_idx, ent_u | ((uint32_t)(TS_MODE_ROOT << 1) << 16));      /* the colour goes straight to the pixel */
-        }
+/* ------------------------------------------------------------------ primary rays
+ * Generation 0 has no queue: its "rays" are the band's pixel items (8x8 tiles, 64 items each: coherent waves), item v sits in
+ * slot v, and both the intersect and the shade kernel compute the camera ray from the item number (rounds 1-2 had a kernel of
+ * its own write 64 bytes per pixel that the next two kernels read back). */
+enum { EU_PR_NONE = 0, EU_PR_PAD = 1, EU_PR_CROSS = 2, EU_PR_CHECKER = 3, EU_PR_RAY = 4 };
+#define EU_WF_ENT_MISS 0xffffffffu       /* EuWfHit::ent: the ray hit nothing */
+#define EU_WF_ENT_SPECIAL 0xfffffffeu    /* generation 0: a pixel without a ray (padding row, cross-hair, checkerboard): the shade kernel writes it */
+#define EU_WF_ENT_DEAD 0xfffffffdu       /* generation 0: an item outside the band */
+struct EuPrimary { uint32_t status, out_idx, px_x, px_y; };
+
+template <int D, class P>
+EU_DEV EuPrimary wf_primary_ray(const EuScene &S, const EuDevCamera &cam, const EuDevFrame &fr, int cam_ent, uint32_t item, real *o, real *d) {
+    EuPrimary pr = {EU_PR_NONE, 0u, 0u, 0u};
+    uint32_t ry;
+    if (fr.single_pixel) {      /* Environment::trace_screen_point: exactly one item */
+        if (item != 0) return pr;
+        pr.px_x = fr.single_x; pr.px_y = fr.single_y; ry = 0; pr.out_idx = 0;
+    } else {
+        const uint32_t tile = item >> 6, within = item & 63u;   /* 8x8 pixel tiles: coherent waves */
+        pr.px_x = (tile % fr.tiles_x) * 8 + (within & 7);
+        ry = fr.band_row0 + (tile / fr.tiles_x) * 8 + (within >> 3);
+        if (pr.px_x >= fr.width || ry >= fr.local_rows || ry >= fr.band_row0 + fr.band_rows) return pr;
+        pr.out_idx = ry * fr.width + pr.px_x;
+        if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
+            const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
+            pr.px_y = fr.row_begin + gstrip * 8 + (ry & 7);
+            if (pr.px_y >= fr.row_end) { pr.status = EU_PR_PAD; return pr; }   /* padding rows of the last strip: defined contents */
+        } else pr.px_y = fr.row_begin + ry;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) B.seg_count[blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
-    wf_flush_counters(counters, cnt);
+    /* Environment::render's cross-hair (universe/mod.rs:321-333) */
+    const uint32_t hw = fr.width / 2, hh = fr.height / 2;
+    if (fr.debug_crosshair && ((pr.px_x == hw && (pr.px_y == hh - 1 || pr.px_y == hh + 1)) || (pr.px_y == hh && (pr.px_x == hw - 1 || pr.px_x == hw + 1)))) {
+        pr.status = EU_PR_CROSS;
+        return pr;
+    }
+    /* trace_unknown: no material at the camera -> trace_screen_point's checkerboard (universe/mod.rs:253-271,387-395) */
+    if (cam_ent < 0) { pr.status = EU_PR_CHECKER; return pr; }
+    /* camera ray (d3/entity/camera.rs:164-185, d4/entity/camera.rs:155-176) */
+    const int sw = (int)fr.width, sh = (int)fr.height;
+    const real rel_x = (real)((int)pr.px_x - sw / 2) + (real)(1 - sw % 2) / R(2.0);
+    const real rel_y = (real)((int)pr.px_y - sh / 2) + (real)(1 - sh % 2) / R(2.0);
+    real dl[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const real center = cam.location[i] + cam.forward[i] * cam.dist;
+        const real p = center + (cam.up[i] * rel_y) + (cam.right[i] * rel_x);
+        dl[i] = p - cam.location[i];
+        o[i] = cam.location[i];
+    }
+    vnormalize<D>(dl, d);
+    P::material_apply(S, (uint32_t)cam_ent, d, false);
+    pr.status = EU_PR_RAY;
+    return pr;
 }
 
 /* ------------------------------------------------------------------ trace_closest */
-template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */>
-__global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t root_base,
-                                                                      EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {
-    extern __shared__ uint64_t lds_dyn[];
+/* G0: the kernel of generation 0 (rays from the pixel index; `gen` is 0, camera and frame are used) is a separate instantiation:
+ * the 58 SGPRs of camera + frame and the primary-ray code (Material::enter: the interpreter's RPN machine) would otherwise weigh on
+ * the kernels of every generation, and the intersect loop is out of SGPRs as it is. */
+template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); else a private array of HSCAP entries */, class P, bool G0>
+EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen, const EuDevCamera &cam, const EuDevFrame &fr,
+                              const EuWfBuffers &B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov, uint64_t *lds_dyn) {
+    constexpr bool g0 = G0;
     EuScene S;
     S.init(scene_g);      /* wave-uniform addresses: the scene arrives through scalar loads */
-    typename std::conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
+    typename eu_conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
     if constexpr (HSCAP == 0) {
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double *hs_t = (double *)(lds_dyn);
+        real *hs_t = (real *)(lds_dyn);
         uint32_t *hs_c = (uint32_t *)(hs_t + (EU_WF_BLOCK / 64) * hs_cap * 64);
         HS.t = hs_t + wave * hs_cap * 64 + lane;
         HS.c = hs_c + wave * hs_cap * 64 + lane;
@@ -307,111 +262,78 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
     if ((threadIdx.x & 63) == 16) cnt.prof[16] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_wave_barrier();
 #endif
-#ifdef EU_PROFILE_ISECT       /* diagnostic build: cycles per entity slot (phase[e], e < 14), ray load (14), result store (15) */
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
-#define IS_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[(k)] += now_ - last_; last_ = now_; } while (0)
-#define IS_START() do { last_ = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define IS_STAMP(k) do { } while (0)
-#define IS_START() do { } while (0)
-#endif
     const uint32_t in = gen & 1u;
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
-    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    int cam_ent = -1;
+    uint32_t total;
+    if (g0) {      /* every camera ray starts at the camera (get_ray_point, d3/entity/camera.rs:147-153): material_at(origin) is one value per frame */
+        cam_ent = P::material_at(S, cam.location);
+        total = fr.n_tiles * 64u;
+    } else total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     SHP(cnt, 8);      /* kernel prologue: scene header, queue prefix */
+    const bool trace_any = !g0 || cam.max_depth != 0;      /* trace() with depth 0 goes straight to the background: generation 0 only marks the pixels */
     {
         /* software pipeline: the next ray of this lane is located and its loads are issued before the current one is
          * intersected (the kernel keeps 3 waves per SIMD: too few to hide an HBM round trip behind other waves) */
         const uint32_t v_step = gridDim.x * blockDim.x;
         uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
         uint32_t i_next = 0;
-        double o_next[D], d_next[D];
+        real o_next[D], d_next[D];
 #pragma unroll
         for (int k = 0; k < D; k++) { o_next[k] = R(0.0); d_next[k] = R(0.0); }
-        if (v < total) {
+        if (!g0 && v < total) {
             i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v);
             wf_load_ray<D>(B, in, i_next, o_next, d_next);
         }
         for (; v < total; v += v_step) {
-            IS_START();
-            const uint32_t i = i_next;
-            double o[D], d[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) { o[k] = o_next[k]; d[k] = d_next[k]; }
-#if EU_ISECT_PREFETCH
-            if (v + v_step < total) {
-                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
-                wf_load_ray<D>(B, in, i_next, o_next, d_next);
-            }
+            uint32_t i = i_next;
+            real o[D], d[D];
+            bool live = true;
+            uint32_t out_idx = 0;
+            if (g0) {
+                i = v;
+                const EuPrimary pr = wf_primary_ray<D, P>(S, cam, fr, cam_ent, v, o, d);
+                out_idx = pr.out_idx;
+                if (pr.status != EU_PR_RAY) {
+                    EuWfHit h;
+                    h.t = R(0.0); h.code = 0; h.ent = pr.status == EU_PR_NONE ? EU_WF_ENT_DEAD : EU_WF_ENT_SPECIAL;
+#if EU_REAL_BITS == 32
+                    h.pad = 0;
 #endif
-            cnt.rays++;
-            SHP(cnt, 9);      /* per batch: current ray out of the prefetch registers, next ray located and requested */
-#ifdef EU_EXP_DUMMY_VALU      /* experiment ("what an instruction costs"): EU_EXP_DUMMY_VALU extra f64 VALU instructions per ray batch, 4 independent chains */
-            {
-                double a0 = o[0], a1 = o[1], a2 = d[0], a3 = d[1];
-#pragma unroll
-                for (int q = 0; q < EU_EXP_DUMMY_VALU / 4; q++) {
-                    asm volatile("v_add_f64 %0, %0, %0" : "+v"(a0)); asm volatile("v_add_f64 %0, %0, %0" : "+v"(a1));
-                    asm volatile("v_add_f64 %0, %0, %0" : "+v"(a2)); asm volatile("v_add_f64 %0, %0, %0" : "+v"(a3));
+                    B.hit[i] = h;
+                    live = false;
                 }
-                if (a0 + a1 + a2 + a3 == R(12345.678)) cnt.errors++;
-            }
-#endif
-#ifdef EU_EXP_DUMMY_SALU      /* experiment: EU_EXP_DUMMY_SALU extra SALU instructions per ray batch */
-            {
-                uint32_t s0 = gen;
+            } else {
 #pragma unroll
-                for (int q = 0; q < EU_EXP_DUMMY_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
-                if (s0 == 0x12345678u) cnt.errors++;
-            }
+                for (int k = 0; k < D; k++) { o[k] = o_next[k]; d[k] = d_next[k]; }
+#if EU_ISECT_PREFETCH
+                if (v + v_step < total) {
+                    i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+                    wf_load_ray<D>(B, in, i_next, o_next, d_next);
+                }
 #endif
-            IS_STAMP(14);
+            }
+            SHP(cnt, 9);      /* per batch: current ray out of the prefetch registers, next ray located and requested */
+            if (live) {
             /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  A wave whose rays are
              * all regular (finite, no zero direction component) evaluates box chains with one product per dot product
              * (chain_matrices_box); should a lane then report a non-finite hit point, the wave's rays are traced once more the generic way. */
             bool have = false;
-            double best_t = R(0.0);
-            uint32_t best_code = 0, best_ent = 0xffffffffu;
-            bool use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull;
-#ifdef EU_PROFILE_ISECT
-            use_box = false;
-#endif
-            for (;;) {
-            bool fail = false;
-            LaneCounters c1 = cnt;
-            have = false; best_t = R(0.0); best_code = 0; best_ent = 0xffffffffu;
-            for (uint32_t e = 0; e < S.n_entities; e++) {
-                const EuScene::EntityView E = S.entity(e);
-                if (E.surface < 0) continue;
-#if defined(EU_PROFILE_ISECT) || defined(EU_DEBUG_SKIP)      /* EU_DEBUG_SKIP_ENTITIES (bit e = leave entity e out): cost per entity from PMC / time deltas */
-                if (((scene_words >> 24) >> e) & 1u) continue;
-#endif
-#ifdef EU_PROFILE_ISECT      /* one stamp per entity, after the lanes have reconverged (a lane-level stamp would count a neighbour's work twice) */
-                if (!(E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d))) {
-                    double t = R(0.0); uint32_t code = 0;
-                    const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
-                    if (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = e; }
+            real best_t = R(0.0);
+            uint32_t best_code = 0, best_ent = EU_WF_ENT_MISS;
+            if (trace_any) {
+                cnt.rays++;
+                bool use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull;
+                for (;;) {
+                    bool fail = false;
+                    LaneCounters c1 = cnt;
+                    have = false; best_t = R(0.0); best_code = 0; best_ent = EU_WF_ENT_MISS;
+                    P::trace_closest(S, o, d, HS, c1, use_box, fail, have, best_t, best_code, best_ent);
+                    if (__ballot(fail) == 0ull) { cnt = c1; break; }
+                    use_box = false;
                 }
-                __builtin_amdgcn_wave_barrier();
-                IS_STAMP(e < 14 ? e : 13);
-#else
-                if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
-                double t = R(0.0); uint32_t code = 0;
-                const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, HS, c1, t, code, use_box, fail);
-                if (n == 0) continue;
-                if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
-#endif
             }
-            if (__ballot(fail) == 0ull) { cnt = c1; break; }
-            use_box = false;
-            }
-#if !EU_ISECT_PREFETCH      /* (123 instead of 137 VGPRs; measured equal) */
-            if (v + v_step < total) {
-                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
-                wf_load_ray<D>(B, in, i_next, o_next, d_next);
-            }
-#endif
             {
                 EuWfHit h;
                 h.t = best_t; h.code = best_code; h.ent = best_ent;
@@ -420,46 +342,58 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_k
 #endif
                 B.hit[i] = h;
             }
-            if (gen == 0 && hit_t_aov) hit_t_aov[B.ray_pa[0][i].x] = have ? best_t : -R(1.0);      /* a primary ray's parent is its pixel */
+            if (g0 && hit_t_aov) hit_t_aov[out_idx] = have ? best_t : -R(1.0);
+            }
+#if !EU_ISECT_PREFETCH
+            if (!g0 && v + v_step < total) {
+                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+                wf_load_ray<D>(B, in, i_next, o_next, d_next);
+            }
+#endif
             SHP(cnt, 10);     /* per batch: entity loop's end, result store */
-            IS_STAMP(15);
         }
     }
-#ifdef EU_PROFILE_ISECT
-    for (int q = 0; q < 16; q++) {
-        unsigned long long v = ph[q];
-        for (int off = 32; off > 0; off >>= 1) { unsigned long long w2 = __shfl_down(v, off); v = w2 > v ? w2 : v; }
-        if ((threadIdx.x & 63) == 0) atomicAdd(&counters->phase[q], v);
-    }
-#endif
     wf_flush_counters(counters, cnt);
 }
 
-/* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
-template <int D, bool SCENE_LDS>
-__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth /* diagnostic builds: | EU_DEBUG_SKIP_SHADE << 16 */, double time_s,
-                                                                  EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
-#ifdef EU_DEBUG_SKIP      /* EU_DEBUG_SKIP_SHADE bits (in max_depth's high half): 1 constant background, 2 constant opaque surface colour, 4 ratio 0 */
-    const uint32_t dbg_shade = max_depth >> 16;
-    max_depth &= 0xffffu;
-#endif
+template <int D, int HSCAP>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect_kernel(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen,
+                                                                      EuWfBuffers B, EuDevCounters *counters) {
     extern __shared__ uint64_t lds_dyn[];
+    const EuDevCamera cam = {};
+    const EuDevFrame fr = {};
+    wf_intersect_body<D, HSCAP, EuInterp<D>, false>(scene_g, hs_cap, gen, cam, fr, B, counters, nullptr, lds_dyn);
+}
+template <int D, int HSCAP>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect0_kernel(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,
+                                                                       EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {
+    extern __shared__ uint64_t lds_dyn[];
+    wf_intersect_body<D, HSCAP, EuInterp<D>, true>(scene_g, hs_cap, 0u, cam, fr, B, counters, hit_t_aov, lds_dyn);
+}
+
+/* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
+template <int D, bool SCENE_LDS, class P, bool G0>
+EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, real time_s, const EuDevCamera &cam, const EuDevFrame &fr,
+                          const EuWfBuffers &B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb,
+                          uint64_t *lds_dyn) {
+    constexpr bool g0 = G0;
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
     __syncthreads();
-    /* The hit entity differs from lane to lane, so the surface / colour-program records are read with per-lane
+    /* The hit entity differs from lane to lane, so the interpreter reads the surface / colour-program records with per-lane
      * addresses: from a copy of the flat scene in LDS (the L1 is swept by the ray streams, a global read of the
-     * scene usually goes to L2). */
+     * scene usually goes to L2).  (A scene-specialised policy has the records as constants.) */
     const uint64_t *scene_base = scene_g;
-    double *color_stack = (double *)lds_dyn;       /* surface_color's operand stack: color_depth RGBA entries per lane (dynamic LDS) */
+    real *color_stack = (real *)lds_dyn;       /* surface_color's operand stack: color_depth RGBA entries per lane (dynamic LDS) */
     if constexpr (SCENE_LDS) {
         for (uint32_t i = threadIdx.x; i < scene_words; i += EU_WF_BLOCK) lds_dyn[i] = scene_g[i];
         __syncthreads();
         scene_base = lds_dyn;
-        color_stack = (double *)(lds_dyn + scene_words);
+        color_stack = (real *)(lds_dyn + scene_words);
     }
     EuScene S;
     S.init(scene_base);
+    S.wrt = scene_g;
     LaneCounters cnt = {0, 0, 0, 0};
 #ifdef EU_PROFILE_SHADE_WAVE
     __shared__ unsigned long long prof_rows[EU_WF_BLOCK / 64][17];
@@ -468,21 +402,22 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
     if ((threadIdx.x & 63) == 16) cnt.prof[16] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_wave_barrier();
 #endif
-#ifdef EU_PROFILE_PHASES
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, last2_ = 0;
-#endif
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
     const uint32_t out_base = blockIdx.x * B.seg_cap;
     const uint32_t node_base = gen * B.ray_cap;       /* node id of queue slot q: node_base + q */
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
-    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    int cam_ent = -1;
+    uint32_t total;
+    if (g0) { cam_ent = P::material_at(S, cam.location); total = fr.n_tiles * 64u; }
+    else total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     /* Rays are taken in windows of EU_WF_WIN per workgroup and counting-sorted in LDS by the entity they
      * hit, so that a wave shades (mostly) one surface: a wall ray costs ~500 instructions, a glass ray
      * (Fresnel + Snell + rotation) ~2500, and unsorted they would share waves. */
     __shared__ uint32_t sorted[EU_WF_WIN];
     __shared__ uint32_t hist[EU_WF_KEYS], offs[EU_WF_KEYS];
+    __shared__ uint32_t n_sorted;
     {
         /* a generation too small to give every workgroup a full window is cut into smaller ones: a window's rays are
          * shaded EU_WF_BLOCK at a time, so its latency (the kernel's critical path) shrinks with it */
@@ -499,19 +434,22 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
                 const uint32_t v = wbase + k * EU_WF_BLOCK + threadIdx.x;
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
                 if (v < wbase + win && v < total) {
-                    myq[k] = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+                    myq[k] = g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v);
                     const uint32_t he = B.hit[myq[k]].ent;
-                    mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
-                    myrank[k] = atomicAdd(&hist[mykey[k]], 1u);
+                    if (he == EU_WF_ENT_DEAD) B.node_kind[node_base + myq[k]] = (uint8_t)TS_NONE;      /* (generation 0 only) nothing to shade, nothing to resolve */
+                    else {
+                        mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
+                        myrank[k] = atomicAdd(&hist[mykey[k]], 1u);
+                    }
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } }
+            if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } n_sorted = run; }
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) if (mykey[k] != 0xffffffffu) sorted[offs[mykey[k]] + myrank[k]] = myq[k];
             __syncthreads();
-            const uint32_t n_live = wbase < total ? (total - wbase < win ? total - wbase : win) : 0u;
+            const uint32_t n_live = n_sorted;
 #pragma unroll 1
             for (uint32_t sub = 0; sub * EU_WF_BLOCK < n_live; sub++) {
             const uint32_t sidx = sub * EU_WF_BLOCK + threadIdx.x;
@@ -521,67 +459,70 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kerne
             const uint32_t nid = node_base + i;
             /* children of this ray: 0 = transmission, 1 = reflection; c_sm = slot | delivery mode << 1 (trace_nodes.h) */
             uint32_t n_child = 0;
-            double c_o[2][D], c_d[2][D];
+            real c_o[2][D], c_d[2][D];
             uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_sm[2] = {0, 0};
             bool bg_miss = false;
             if (live) {
                 WF_STAMP(1);
-                const uint2 pa = B.ray_pa[in][i];
-                const uint32_t parent = pa.x, aux = pa.y;
-                const uint32_t ent = aux & 0xffffu, sm = (aux >> 16) & 7u;
-                double o[D], d[D];
-wf_load_ray<D>(B, in, i, o, d);
+                uint32_t parent, ent, sm;
+                real o[D], d[D];
                 const EuWfHit hit = B.hit[i];
-                const uint32_t hit_ent = hit.ent;
+                uint32_t hit_ent = hit.ent;
+                if (g0) {
+                    const EuPrimary pr = wf_primary_ray<D, P>(S, cam, fr, cam_ent, i, o, d);
+                    parent = pr.out_idx; ent = (uint32_t)cam_ent; sm = (uint32_t)(TS_MODE_ROOT << 1);      /* the colour goes straight to the pixel */
+                    if (pr.status != EU_PR_RAY) {      /* (hit_ent == EU_WF_ENT_SPECIAL) a pixel without a ray */
+                        hit_ent = EU_WF_ENT_SPECIAL;
+                        if (hit_t_aov) hit_t_aov[pr.out_idx] = -R(1.0);
+                        if (pr.status == EU_PR_PAD) rgba[pr.out_idx] = 0u;
+                        else if (pr.status == EU_PR_CROSS) {
+                            rgba[pr.out_idx] = 0xff0000ffu;
+                            if (point_rgb) { point_rgb[0] = R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = R(0.0); }
+                        } else {      /* trace_screen_point's checkerboard (universe/mod.rs:387-395) */
+                            const bool black = (((int)pr.px_x / 8 + (int)pr.px_y / 8) % 2) == 0;
+                            rgba[pr.out_idx] = black ? 0xff000000u : 0xffff00ffu;
+                            if (point_rgb) { point_rgb[0] = black ? R(0.0) : R(1.0); point_rgb[1] = R(0.0); point_rgb[2] = black ? R(0.0) : R(1.0); }
+                        }
+                    }
+                } else {
+                    const uint2 pa = B.ray_pa[in][i];
+                    parent = pa.x; ent = pa.y & 0xffffu; sm = (pa.y >> 16) & 7u;
+                    wf_load_ray<D>(B, in, i, o, d);
+                }
                 uint32_t node_kind = TS_NONE;
-                if (hit_ent == 0xffffffffu) {
+                if (hit_ent == EU_WF_ENT_SPECIAL) {
+                } else if (hit_ent == EU_WF_ENT_MISS) {
                     /* nothing hit: the background colour goes to the parent; handled as a depth-0 "child" below */
 #pragma unroll
                     for (int k = 0; k < D; k++) { c_o[0][k] = o[k]; c_d[0][k] = d[k]; }
                     c_parent[0] = parent; c_sm[0] = sm;
                     n_child = 1; bg_miss = true;
                 } else {
-                    const double best_t = hit.t;
+                    const real best_t = hit.t;
                     const uint32_t best_code = hit.code;
                     HitCtx<D> c;
                     c.finish(best_t, o, d);
-                    hit_normal<D>(S, best_code, o, d, c.loc, c.normal);
+                    P::hit_normal(S, hit_ent, best_code, o, d, c.loc, c.normal);
                     c.classify();
                     WF_STAMP(2);
-                    const EuScene::EntityView HE = S.entity(hit_ent);
-                    const EuFlatSurface *F = S.surface((uint32_t)HE.surface);
-#ifdef EU_DEBUG_SKIP
-                    double ratio = (dbg_shade & 4u) ? R(0.0) : reflection_ratio<D>(F, c);
-#else
-                    double ratio = reflection_ratio<D>(F, c);
-#endif
-                    ratio = rust_max(rust_min(ratio, R(1.0)), R(0.0));                          /* surface.rs:145-147 */
-
+                    SurfaceEval<D> E;
+                    P::surface(S, hit_ent, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK, E);
+                    const real ratio = E.ratio;
                     WF_STAMP(3);
                     bool have_inter = false, need_trans = false;
                     Rgba inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
-                    uint32_t spx = 0;
+                    const uint32_t spx = E.spx;
                     int dest = -1;
-                    if (!(ratio >= R(1.0))) {                                                /* get_intersection_color, surface.rs:62-117 */
-#ifdef EU_DEBUG_SKIP
-                        const Rgba sc = (dbg_shade & 2u) ? Rgba{R(0.25), R(0.5), R(0.75), R(1.0)} : surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
-#else
-                        const Rgba sc = surface_color<D>(S, F, c, time_s, cnt, color_stack + threadIdx.x, EU_WF_BLOCK);
-#endif
-                        WF_SUB(8);
-                        spx = to_pixel4(sc, cnt);
-                        WF_SUB(9);
-                        if ((spx >> 24) == 255u) { inter = sc; have_inter = true; }
+                    if (E.have_color) {                                                /* get_intersection_color, surface.rs:62-117 */
+                        if (!E.translucent) { inter = E.sc; have_inter = true; }
                         else {
-                            threshold_direction<D>(F, c, c_d[0]);
-                            WF_SUB(10);
 #pragma unroll
-                            for (int k = 0; k < D; k++) c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0);
-                            dest = c.exiting ? material_at<D>(S, c_o[0]) : (int)hit_ent;
+                            for (int k = 0; k < D; k++) { c_d[0][k] = E.thr[k]; c_o[0][k] = c.loc[k] + -c.nc[k] * EU_EPS * R(128.0); }
+                            dest = c.exiting ? P::material_at(S, c_o[0]) : (int)hit_ent;
                             WF_SUB(11);
                             if (dest >= 0) {
-                                material_apply<D>(S, S.entity(ent).material, c_d[0], true);
-                                material_apply<D>(S, S.entity((uint32_t)dest).material, c_d[0], false);
+                                P::material_apply(S, ent, c_d[0], true);
+                                P::material_apply(S, (uint32_t)dest, c_d[0], false);
                                 need_trans = true;
                             }
                         }
@@ -590,11 +531,11 @@ wf_load_ray<D>(B, in, i, o, d);
                     const bool need_refl = !(ratio <= R(0.0));                                /* get_reflection_color, surface.rs:119-139 */
                     const uint32_t rs = need_trans ? 1u : 0u;        /* reflection goes to child slot rs in the arrays */
                     if (need_refl) {
-                        const double dn = vdot<D>(c.dir, c.nc);
+                        const real dn = vdot<D>(c.dir, c.nc);
 #pragma unroll
                         for (int k = 0; k < D; k++) {
-                            const double rd = c.nc[k] * -R(2.0) * dn + c.dir[k];              /* surface.rs:246-256 */
-                            const double ro = c.loc[k] + c.nc[k] * EU_EPS * R(128.0);
+                            const real rd = c.nc[k] * -R(2.0) * dn + c.dir[k];              /* surface.rs:246-256 */
+                            const real ro = c.loc[k] + c.nc[k] * EU_EPS * R(128.0);
                             if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
                         }
                     }
@@ -633,14 +574,10 @@ wf_load_ray<D>(B, in, i, o, d);
 #pragma unroll 1
             for (uint32_t k = 0; k < 2; k++) {      /* constant indices only: a run-time indexed private array would live in scratch */
                 if (bg_only && k < n_child) {
-                    double dd[D];
+                    real dd[D];
 #pragma unroll
                     for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
-#ifdef EU_DEBUG_SKIP
-                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], (dbg_shade & 1u) ? Rgba{R(0.1), R(0.2), R(0.3), R(1.0)} : ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
-#else
-                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D>(S, dd, cnt), cnt, rgba, point_rgb);
-#endif
+                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D, P>(S, dd, cnt), cnt, rgba, point_rgb);
                 }
             }
             WF_STAMP(6);
@@ -660,41 +597,52 @@ wf_load_ray<D>(B, in, i, o, d);
         }
     }
     __syncthreads();
-#ifdef EU_PROFILE_PHASES
-    for (int q = 0; q < 16; q++) {
-        unsigned long long v = ph[q];
-        for (int off = 32; off > 0; off >>= 1) { unsigned long long w2 = __shfl_down(v, off); v = w2 > v ? w2 : v; }
-        if ((threadIdx.x & 63) == 0) atomicAdd(&counters->phase[q], v);
-    }
-#endif
     if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
     wf_flush_counters(counters, cnt);
+}
+
+template <int D, bool SCENE_LDS>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, real time_s,
+                                                                  EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
+    extern __shared__ uint64_t lds_dyn[];
+    const EuDevCamera cam = {};
+    const EuDevFrame fr = {};
+    wf_shade_body<D, SCENE_LDS, EuInterp<D>, false>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn);
+}
+template <int D, bool SCENE_LDS>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,
+                                                                   EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb) {
+    extern __shared__ uint64_t lds_dyn[];
+    wf_shade_body<D, SCENE_LDS, EuInterp<D>, true>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn);
 }
 
 /* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes
  * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
  * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass */
-template <int D>
-__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
-    LaneCounters cnt = {0, 0, 0, 0};
+EU_DEV void wf_resolve_generation(uint32_t gen, uint32_t total0, const EuWfBuffers &B, LaneCounters &cnt, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb,
+                                  uint32_t *pref, uint32_t *wave_tot) {
     const uint32_t node_base = gen * B.ray_cap;
+    const bool g0 = gen == 0;
+    const uint32_t total = g0 ? total0 : wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        const uint32_t nid = node_base + (g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v));
+        const uint32_t kind = B.node_kind[nid];
+        if (kind == TS_NONE) continue;
+        const EuTsNode *N = B.nodes + nid;
+        Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
+        if (kind != TS_COMBINE_INTER) {
+            const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
+            res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
+        }
+        ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
+    }
+}
+
+__global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, uint32_t total0, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
+    LaneCounters cnt = {0, 0, 0, 0};
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
     __shared__ uint32_t wave_tot[4];
-    const uint32_t total = wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
-    {
-        for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
-            const uint32_t nid = node_base + wf_map_index(pref, B.n_seg, B.seg_cap, v);
-            const uint32_t kind = B.node_kind[nid];
-            if (kind == TS_NONE) continue;
-            const EuTsNode *N = B.nodes + nid;
-            Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
-            if (kind != TS_COMBINE_INTER) {
-                const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
-                res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
-            }
-            ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
-        }
-    }
+    wf_resolve_generation(gen, total0, B, cnt, rgba, point_rgb, pref, wave_tot);
     wf_flush_counters(counters, cnt);
 }
 

@@ -18,6 +18,11 @@ from . import _capi
 from . import textures as _textures
 
 
+# Process-wide defaults for Environment.renderer() (tests switch the whole suite between the interpreter and the specialised kernels
+# with these; an Environment's own configure() wins)
+DEFAULT_RENDERER_OPTS = {}
+
+
 class ParserError(Exception):
     """scene.rs:524-552; `kind` is the variant name."""
 
@@ -91,16 +96,70 @@ class Environment:
     def dim(self):
         return self.info.dim
 
+    # How renderers are created (eu_renderer_opts): set before the first render.
+    #   specialize: "off" (the ahead-of-time kernels interpret the flat scene), "sync" (kernels specialised for this scene are compiled
+    #               with hiprtc when the renderer is created, a few seconds the first time, cached on disk), None = the library default
+    #   kernel: None / "wavefront" / "stack";  streams, ray_factor, band_pixels: 0 = default;  shade_scene_global: test hook
+    def configure(self, specialize=None, kernel=None, streams=0, ray_factor=0.0, band_pixels=0, cache_dir=None, shade_scene_global=False,
+                  jit_flags=None):
+        if self._renderers:
+            raise RuntimeError("configure() before the first renderer exists")
+        self._opts = dict(specialize=specialize, kernel=kernel, streams=streams, ray_factor=ray_factor, band_pixels=band_pixels,
+                          cache_dir=cache_dir, shade_scene_global=shade_scene_global, jit_flags=jit_flags)
+        return self
+
+    def _renderer_opts(self):
+        o = dict(DEFAULT_RENDERER_OPTS)
+        o.update({k: v for k, v in getattr(self, "_opts", {}).items() if v not in (None, 0, 0.0, False)})
+        spec = {None: _capi.EU_SPECIALIZE_AUTO, "auto": _capi.EU_SPECIALIZE_AUTO, "off": _capi.EU_SPECIALIZE_OFF, "sync": _capi.EU_SPECIALIZE_SYNC}[o.get("specialize")]
+        kern = {None: _capi.EU_KERNEL_AUTO, "wavefront": _capi.EU_KERNEL_WAVEFRONT, "stack": _capi.EU_KERNEL_STACK}[o.get("kernel")]
+        cache = o.get("cache_dir")
+        flags = o.get("jit_flags")
+        return _capi.RendererOpts(C.sizeof(_capi.RendererOpts), kern, spec, int(o.get("streams") or 0), float(o.get("ray_factor") or 0.0),
+                                  int(o.get("band_pixels") or 0), cache.encode() if cache else None,
+                                  _capi.EU_RENDERER_SHADE_SCENE_GLOBAL if o.get("shade_scene_global") else 0, 0,
+                                  flags.encode() if flags else None)
+
     def renderer(self, device=0):
         if device not in self._renderers:
             L = self._L
             out = C.c_void_p()
             err = C.create_string_buffer(512)
-            rc = L.eu_renderer_create(self._scene, device, C.byref(out), err, len(err))
+            opts = self._renderer_opts()
+            rc = L.eu_renderer_create_opts(self._scene, device, C.byref(opts), C.byref(out), err, len(err))
             if rc != _capi.EU_OK:
                 raise EuError(rc, err.value.decode())
             self._renderers[device] = out
         return self._renderers[device]
+
+    def jit_info(self, device=0):
+        """What eu_renderer_jit_info says about this renderer's scene-specialised kernels."""
+        info = _capi.JitInfo()
+        rc = self._L.eu_renderer_jit_info(self.renderer(device), C.byref(info))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return {"requested": bool(info.requested), "active": bool(info.active), "from_cache": bool(info.from_cache),
+                "hit_stack_entries": info.hit_stack_entries, "compile_ms": info.compile_ms, "key": info.key.decode()}
+
+    def jit_source(self):
+        """The HIP source of this scene's specialised kernels (no GPU needed)."""
+        src, key = C.c_void_p(), C.create_string_buffer(40)
+        rc = self._L.eu_scene_jit_source(self._scene, C.byref(src), key)
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        try:
+            return C.string_at(src.value).decode(), key.value.decode()
+        finally:
+            self._L.eu_free(src)
+
+    def jit_precompile(self, cache_dir=None):
+        """Compile this scene's specialised kernels for gfx950 into the cache (no GPU needed); returns eu_jit_info as a dict."""
+        info, err = _capi.JitInfo(), C.create_string_buffer(1 << 16)
+        rc = self._L.eu_scene_jit_precompile(self._scene, cache_dir.encode() if cache_dir else None, C.byref(info), err, len(err))
+        if rc != _capi.EU_OK:
+            raise EuError(rc, err.value.decode())
+        return {"from_cache": bool(info.from_cache), "compile_ms": info.compile_ms, "key": info.key.decode(),
+                "hit_stack_entries": info.hit_stack_entries}
 
     # -- Environment trait
     def max_depth(self):
@@ -185,7 +244,8 @@ class Environment:
             out = C.c_void_p()
             err = C.create_string_buffer(512)
             arr = (C.c_int * len(key))(*key)
-            rc = L.eu_multi_create(self._scene, arr, len(key), C.byref(out), err, len(err))
+            opts = self._renderer_opts()
+            rc = L.eu_multi_create_opts(self._scene, arr, len(key), C.byref(opts), C.byref(out), err, len(err))
             if rc != _capi.EU_OK:
                 raise EuError(rc, err.value.decode())
             self._multis[key] = out

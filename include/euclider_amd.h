@@ -25,6 +25,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)      /* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#endif
 
 #define EU_OK 0
 #define EU_ERR_INVALID_ARGUMENT (-1)
@@ -112,8 +115,55 @@ const void *eu_scene_flat(const eu_scene *, size_t *bytes);         /* flattened
 uint32_t eu_frame_local_rows(const eu_frame *);   /* rows of the output buffer for this frame/partition */
 
 int eu_device_count(void);
+
+/* How a renderer works (every field 0 = the default).  Pass it to eu_renderer_create_opts; eu_renderer_create uses the defaults.
+ * (Rounds 1-2 read these from environment variables; a library built with -DEU_DIAGNOSTICS still honours EU_KERNEL,
+ * EU_SPECIALIZE, EU_WF_STREAMS, EU_WF_RAY_FACTOR and EU_WF_BAND_PIXELS on top of the struct, for the profiling scripts.) */
+#define EU_KERNEL_AUTO 0u          /* the wavefront pipeline; the stack kernel only to re-trace a frame that overflowed the ray queues */
+#define EU_KERNEL_WAVEFRONT 1u
+#define EU_KERNEL_STACK 2u         /* the persistent stack-based kernel for everything (several times slower; A/B checks) */
+#define EU_SPECIALIZE_AUTO 0u      /* currently = OFF */
+#define EU_SPECIALIZE_OFF 1u       /* the ahead-of-time kernels, which interpret the flat scene */
+#define EU_SPECIALIZE_SYNC 2u      /* eu_renderer_create compiles trace kernels specialised for THIS scene with hiprtc (a few seconds the
+                                      first time; the code object is cached on disk by content) and every frame uses them; if the compilation
+                                      fails the renderer falls back to the interpreter kernels and eu_renderer_jit_info says so */
+#define EU_RENDERER_SHADE_SCENE_GLOBAL 1u   /* flags: the interpreter's shade kernel reads the scene from global memory, not from its LDS copy
+                                               (what scenes above ~40 KB get anyway; here so that tests can reach that variant) */
+typedef struct {
+    uint32_t struct_size;        /* sizeof(eu_renderer_opts) of the caller: the struct may grow */
+    uint32_t kernel;             /* EU_KERNEL_* */
+    uint32_t specialize;         /* EU_SPECIALIZE_* */
+    uint32_t streams;            /* band pipelines in flight per frame, 1..4 (0: 2 for scenes whose recursion branches, else 1) */
+    double ray_factor;           /* ray-queue slots per pixel and generation (0: 4.0); a frame that needs more is reported through
+                                    EU_ERR_CAPACITY (asynchronous calls) or traced again by the stack kernel (eu_render, eu_render_multi) */
+    uint64_t band_pixels;        /* pixels per wavefront pass (0: 4 Mi): larger frames are traced in bands of whole 8-row tiles */
+    const char *cache_dir;       /* where specialised code objects are kept (NULL: $XDG_CACHE_HOME/euclider_amd or ~/.cache/euclider_amd);
+                                    the directory jit_cache next to the library is consulted first (read-only) */
+    uint32_t flags;              /* EU_RENDERER_* */
+    uint32_t reserved;
+    const char *jit_flags;       /* extra compiler flags for the specialised kernels, space-separated (tuning experiments, e.g.
+                                    "-DEU_SHADE_WAVES=4"); part of the cache key; NULL: none */
+} eu_renderer_opts;
+
+typedef struct {
+    int32_t requested;           /* the renderer was asked to specialise */
+    int32_t active;              /* its frames run on the specialised kernels */
+    int32_t from_cache;          /* the code object came from the cache (memory or disk), not from a compilation */
+    uint32_t hit_stack_entries;  /* per-ray hit-stack entries the specialised intersect kernel was compiled for */
+    double compile_ms;           /* time spent in hiprtc (0 when cached) */
+    char key[40];                /* content hash the code object is cached under */
+} eu_jit_info;
+
 int eu_renderer_create(const eu_scene *, int device, eu_renderer **out, char *err, size_t errlen);
+int eu_renderer_create_opts(const eu_scene *, int device, const eu_renderer_opts *opts, eu_renderer **out, char *err, size_t errlen);
 void eu_renderer_destroy(eu_renderer *);
+int eu_renderer_jit_info(eu_renderer *, eu_jit_info *out);
+/* The HIP source eu_renderer_create_opts(EU_SPECIALIZE_SYNC) would compile for this scene (no GPU needed): *source is allocated
+ * with eu_alloc, NUL-terminated; free it with eu_free.  key (optional, >= 40 bytes): the cache key. */
+int eu_scene_jit_source(const eu_scene *, char **source, char *key);
+/* Compiles that source for gfx950 into the cache directory without touching a GPU (what a build step runs so that the first
+ * renderer does not wait); err receives the compiler's log on failure. */
+int eu_scene_jit_precompile(const eu_scene *, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen);
 
 /* Environment::render on the GPU, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
  * rgba_dev: DEVICE buffer of eu_frame_local_rows()*width uint32 (R | G<<8 | B<<16 | 255<<24), rows in
@@ -128,11 +178,10 @@ int eu_renderer_stats(eu_renderer *, eu_stats *);
 int eu_renderer_kernel_ms(eu_renderer *, float *ms);
 /* The same for the most recent min(max_n, 64) launches, oldest first; returns how many were written. */
 int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
-/* Number of frames eu_render had to trace a second time since the renderer was created: a frame whose recursion fans out
- * beyond the ray queues (more than EU_WF_RAY_FACTOR rays per pixel in one generation) is traced again by the stack-based
- * kernel, several times slower; a frame that exhausts the stream kernel's tree-node pool is traced again with a larger pool.
- * The result is the same either way; this counter is how a caller notices the slow path (the asynchronous sequence does not
- * retry, it reports EU_ERR_CAPACITY). */
+/* Number of frames eu_render / eu_render_multi had to trace a second time since the renderer was created: a frame whose
+ * recursion fans out beyond the ray queues (more than eu_renderer_opts.ray_factor rays per pixel in one generation) is traced
+ * again by the stack-based kernel, several times slower.  The result is the same either way; this counter is how a caller
+ * notices the slow path (the asynchronous calls do not retry, they report EU_ERR_CAPACITY). */
 int eu_renderer_retraces(eu_renderer *, uint64_t *count);
 
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
@@ -174,6 +223,7 @@ int eu_sequence_next(eu_sequence *, const uint8_t **rgb_host, uint32_t *width, u
  * devices[0]) of the same image, valid until the next call.  stats: summed over the devices. */
 typedef struct eu_multi eu_multi;
 int eu_multi_create(const eu_scene *, const int *devices, int n_devices, eu_multi **out, char *err, size_t errlen);
+int eu_multi_create_opts(const eu_scene *, const int *devices, int n_devices, const eu_renderer_opts *opts, eu_multi **out, char *err, size_t errlen);
 void eu_multi_destroy(eu_multi *);
 int eu_render_multi(eu_multi *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats);
 const char *eu_multi_error(const eu_multi *);
@@ -224,6 +274,9 @@ int eu_selftest_math(int device, int fn, const double *x, const double *y, doubl
 
 const char *eu_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

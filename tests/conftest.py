@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "interpreter_only: a GPU test that exercises an ahead-of-time kernel variant by name; not repeated on the specialised kernels")
 
 
 @pytest.fixture(scope="session")
@@ -22,3 +23,33 @@ def oracle_lib():
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+# Every GPU test runs twice: on the ahead-of-time kernels that interpret the flat scene ("interp") and on kernels specialised for the
+# test's scene, compiled with hiprtc when its renderer is created ("jit": eu_renderer_opts.specialize = EU_SPECIALIZE_SYNC).  The
+# specialised pass costs a compilation per distinct scene (cached by content), so the random-scene tests take every fourth seed there.
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") is not None and "kernel_path" in metafunc.fixturenames:
+        modes = ["interp"] if metafunc.definition.get_closest_marker("interpreter_only") is not None else ["interp", "jit"]
+        metafunc.parametrize("kernel_path", modes, indirect=True, scope="function")
+
+
+@pytest.fixture(autouse=True)
+def kernel_path(request):
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield None
+        return
+    from euclider_amd import environment
+    if mode == "jit":
+        callspec = getattr(request.node, "callspec", None)
+        seed = callspec.params.get("seed") if callspec is not None else None
+        if isinstance(seed, int) and seed % 4 != 0:
+            pytest.skip("specialised pass: every fourth random scene")
+    saved = dict(environment.DEFAULT_RENDERER_OPTS)
+    environment.DEFAULT_RENDERER_OPTS["specialize"] = "sync" if mode == "jit" else "off"
+    try:
+        yield mode
+    finally:
+        environment.DEFAULT_RENDERER_OPTS.clear()
+        environment.DEFAULT_RENDERER_OPTS.update(saved)

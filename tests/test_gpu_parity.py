@@ -74,6 +74,7 @@ def test_row_tiles_match_full_frame():
     assert np.array_equal(np.concatenate(parts, axis=0), full)
 
 
+@pytest.mark.interpreter_only
 def test_device_math_matches_oracle(oracle_lib):
     import ctypes as C
     from euclider_amd import _capi
@@ -188,16 +189,17 @@ def test_edge_cases():
     env.close()
 
 
-def test_megakernel_variant_matches_wavefront(monkeypatch):
-    """The persistent megakernel (EU_KERNEL=mega, kept for A/B) and the wavefront pipeline give the same frame."""
+@pytest.mark.interpreter_only
+def test_stack_kernel_variant_matches_wavefront():
+    """The persistent stack-based kernel (eu_renderer_opts.kernel = EU_KERNEL_STACK; the re-trace path of overflowing frames) and the
+    wavefront pipeline give the same frame."""
     from euclider_amd import Parser
     path = os.path.join(SCENES, "3d_room.json")
     a = Parser().parse_file(path)
     a.camera.max_depth = 6
     wf = a.render((200, 120), want_hit_t=True)
     a.close()
-    monkeypatch.setenv("EU_KERNEL", "mega")
-    b = Parser().parse_file(path)
+    b = Parser().parse_file(path).configure(kernel="stack")
     b.camera.max_depth = 6
     mk = b.render((200, 120), want_hit_t=True)
     b.close()
@@ -206,7 +208,7 @@ def test_megakernel_variant_matches_wavefront(monkeypatch):
     assert wf.stats["rays"] == mk.stats["rays"] and wf.stats["bg_samples"] == mk.stats["bg_samples"]
 
 
-def test_banded_wavefront_matches_single_pass(monkeypatch):
+def test_banded_wavefront_matches_single_pass():
     """Frames larger than the wavefront band size are traced in several passes; the result must not change."""
     from euclider_amd import Parser
     path = os.path.join(SCENES, "3d_room.json")
@@ -214,8 +216,7 @@ def test_banded_wavefront_matches_single_pass(monkeypatch):
     a.camera.max_depth = 6
     one = a.render((320, 200), want_hit_t=True)
     a.close()
-    monkeypatch.setenv("EU_WF_BAND_PIXELS", str(320 * 24))          # 24-row bands -> 9 passes
-    b = Parser().parse_file(path)
+    b = Parser().parse_file(path).configure(band_pixels=320 * 24)          # 24-row bands -> 9 passes
     b.camera.max_depth = 6
     many = b.render((320, 200), want_hit_t=True)
     strips = b.render((320, 200), strips=(1, 3))
@@ -225,25 +226,25 @@ def test_banded_wavefront_matches_single_pass(monkeypatch):
     assert strips.data.shape[0] > 0
 
 
-def test_shade_kernel_global_scene_variant(monkeypatch):
+@pytest.mark.interpreter_only
+def test_shade_kernel_global_scene_variant():
     """Scenes too large for the shade kernel's LDS copy are read from global memory (eu_wf_shade_kernel<D, false>); none of
     the shipped scenes is that large, so the variant is forced here and must give the same frame."""
     from euclider_amd import Parser
     for scene, depth in (("3d_room.json", 6), ("4d_room.json", 5), ("3d_hallways.json", 8)):
         path = os.path.join(SCENES, scene)
-        monkeypatch.delenv("EU_SHADE_SCENE_GLOBAL", raising=False)
-        a = Parser().parse_file(path)
+        a = Parser().parse_file(path).configure(specialize="off")
         a.camera.max_depth = depth
         lds = a.render((192, 108))
         a.close()
-        monkeypatch.setenv("EU_SHADE_SCENE_GLOBAL", "1")
-        b = Parser().parse_file(path)
+        b = Parser().parse_file(path).configure(specialize="off", shade_scene_global=True)
         b.camera.max_depth = depth
         glb = b.render((192, 108))
         b.close()
         assert np.array_equal(lds.data, glb.data) and lds.stats == glb.stats, scene
 
 
+@pytest.mark.interpreter_only
 def test_error_codes():
     """Bad arguments come back as EU_ERR_* codes, never as a crash (include/euclider_amd.h conventions)."""
     import ctypes as C
@@ -293,35 +294,8 @@ def test_8k_frame_on_one_gpu_in_bands():
     assert full.stats["rays"] == ost["rays"] and full.stats["bg_samples"] == ost["bg_samples"]
 
 
-def test_node_pool_overflow_is_reported_and_retried(monkeypatch):
-    """The stream kernel's ray queues cannot overflow; its tree-node pool can.  With a pool far too small for the frame
-    (EU_TS_NODE_FACTOR) the asynchronous path reports EU_ERR_CAPACITY and the synchronous eu_render still returns the
-    right frame (it enlarges the pool and traces the frame again)."""
-    from euclider_amd import Parser, _capi
-    path = os.path.join(SCENES, "3d_room.json")
-    a = Parser().parse_file(path)
-    a.camera.max_depth = 8
-    good = a.render((1920, 1080))
-    a.close()
-    monkeypatch.setenv("EU_KERNEL", "stream")
-    monkeypatch.setenv("EU_TS_NODE_FACTOR", "0")
-    from euclider_amd import FrameSequence
-    from euclider_amd.environment import EuError
-    b = Parser().parse_file(path)
-    b.camera.max_depth = 8
-    with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
-        seq.submit((1920, 1080))
-        with pytest.raises(EuError) as ei:
-            seq.next()
-        assert ei.value.code == _capi.EU_ERR_CAPACITY
-    retried = b.render((1920, 1080))
-    assert np.array_equal(retried.data, good.data) and retried.stats == good.stats
-    assert b.retraces() >= 1          # the slow path is visible to the caller
-    b.close()
-
-
-def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
-    """Wavefront pipeline: with queues far too small for the frame (EU_WF_RAY_FACTOR), the asynchronous path reports
+def test_queue_overflow_falls_back_to_the_stack_kernel():
+    """Wavefront pipeline: with queues far too small for the frame (eu_renderer_opts.ray_factor), the asynchronous path reports
     EU_ERR_CAPACITY and the synchronous eu_render still returns the right frame (traced again by the stack-based kernel)."""
     from euclider_amd import Parser, _capi
     path = os.path.join(SCENES, "3d_room.json")
@@ -330,15 +304,14 @@ def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
     good = a.render((1920, 1080))
     assert a.retraces() == 0
     a.close()
-    monkeypatch.setenv("EU_KERNEL", "wavefront")
-    monkeypatch.setenv("EU_WF_RAY_FACTOR", "0.05")
-    monkeypatch.setenv("EU_WF_STREAMS", "1")
-    b = Parser().parse_file(path)
+    b = Parser().parse_file(path).configure(kernel="wavefront", ray_factor=0.05, streams=1)
     b.camera.max_depth = 4
     assert b.retraces() == 0
     fell_back = b.render((1920, 1080))
     assert np.array_equal(fell_back.data, good.data) and fell_back.stats == good.stats
     assert b.retraces() == 1          # the slow path is visible to the caller
+    multi = b.render_multi((1920, 1080), [0, 0])          # eu_render_multi re-traces an overflowing device's strips the same way
+    assert np.array_equal(multi.data, good.data) and multi.stats == good.stats
     from euclider_amd import FrameSequence
     from euclider_amd.environment import EuError
     with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
@@ -347,22 +320,6 @@ def test_queue_overflow_falls_back_to_the_stack_kernel(monkeypatch):
             seq.next()
         assert ei.value.code == _capi.EU_ERR_CAPACITY
     b.close()
-
-
-@pytest.mark.parametrize("scene,w,h,depth", CASES)
-def test_stream_kernel_parity(scene, w, h, depth, monkeypatch):
-    """The persistent stream kernel (EU_KERNEL=stream, trace_stream.h) against the oracle: the same bar as the default path."""
-    monkeypatch.setenv("EU_KERNEL", "stream")
-    test_scene_parity(scene, w, h, depth)
-
-
-def test_stream_kernel_partitions_and_single_pixel(monkeypatch):
-    monkeypatch.setenv("EU_KERNEL", "stream")
-    test_row_tiles_match_full_frame()
-    test_strip_partition_matches_full_frame(3, 100)
-    test_trace_screen_point_unquantised()
-    test_time_and_crosshair()
-    test_edge_cases()
 
 
 @pytest.mark.parametrize("ranks,W,H,rows", [(2, 160, 90, None), (3, 200, 100, None), (8, 96, 64, None), (2, 160, 90, (13, 77))])
@@ -385,29 +342,3 @@ def test_render_multi_on_one_device(ranks, W, H, rows):
     if ranks == 2 and rows is None:
         orgb, _, ost = load_scene_file(path).render(W, H, max_depth=6)
         assert np.array_equal(multi.data, orgb) and multi.stats["rays"] == ost["rays"]
-
-
-@pytest.mark.parametrize("scene,w,h,depth,finish_rays", [("3d_room.json", 320, 180, 8, "1000000000"), ("3d_room.json", 320, 180, 8, "60000"),
-                                                         ("3d_hallways.json", 320, 180, 12, "20000"), ("4d_frame.json", 192, 108, 8, "1000000000"),
-                                                         ("4d_cylinders.json", 160, 90, 8, "1000"), ("3d_fresnel_2.json", 128, 128, 10, "1000000000")])
-def test_finish_step_parity(scene, w, h, depth, finish_rays, monkeypatch):
-    """The wavefront pipeline's FINISH step (small generations handed over to the stream kernel in one launch) is learnt from
-    the previous frame's queue lengths: the first frame of a renderer runs every generation, later ones hand over.  All of
-    them must equal the oracle, whatever the threshold makes the hand-over generation."""
-    from euclider_amd import Parser
-    from oracle.scene_loader import load_scene_file
-    monkeypatch.setenv("EU_WF_FINISH_RAYS", finish_rays)
-    path = os.path.join(SCENES, scene)
-    env = Parser().parse_file(path)
-    env.camera.max_depth = depth
-    frames = [env.render((w, h), want_hit_t=True) for _ in range(4)]
-    other = env.render((w // 2, h // 2))          # a different frame size: the learnt generation must not be used for it
-    back = env.render((w, h))
-    env.close()
-    osc = load_scene_file(path)
-    orgb, ohit, ost = osc.render(w, h, max_depth=depth, want_hit_t=True)
-    for k, f in enumerate(frames + [back]):
-        assert np.array_equal(f.data, orgb), "frame %d differs in %d bytes" % (k, int((f.data != orgb).sum()))
-        assert f.stats == {key: ost[key] for key in f.stats}, k
-    o2, _, _ = osc.render(w // 2, h // 2, max_depth=depth)
-    assert np.array_equal(other.data, o2)

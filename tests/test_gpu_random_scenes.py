@@ -12,15 +12,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_case(seed, w, h, depth, time_ms=0, n_entities=None, min_flat_bytes=0):
+def kernel_path_is_jit():
+    from euclider_amd import environment
+    return environment.DEFAULT_RENDERER_OPTS.get("specialize") == "sync"
+
+
+def run_case(seed, w, h, depth, time_ms=0, n_entities=None, min_flat_bytes=0, low_precision=False):
     from euclider_amd import Parser
     from euclider_amd.environment import EuError
     from oracle.scene_loader import OracleScene, default_texture_loader
     text, dim = random_scene(seed, n_entities=n_entities)
-    osc = OracleScene(text, default_texture_loader([ROOT]))
+    osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if low_precision else "")
     orgb, ohit, ost = osc.render(w, h, max_depth=depth, time_ms=time_ms, want_hit_t=True)
     try:
-        env = Parser(texture_dirs=[ROOT]).parse(text)
+        env = Parser(texture_dirs=[ROOT], low_precision=low_precision).parse(text)
     except Exception as e:          # a capacity the kernels were compiled for (reported, never silent)
         pytest.skip("scene %d rejected by the product loader: %s" % (seed, e))
     assert env.info.flat_bytes >= min_flat_bytes
@@ -32,6 +37,8 @@ def run_case(seed, w, h, depth, time_ms=0, n_entities=None, min_flat_bytes=0):
         if e.code == -5:
             pytest.skip("scene %d exceeds a compiled capacity" % seed)
         raise
+    if kernel_path_is_jit():
+        assert env.jit_info()["active"], "the specialised kernels did not build for scene %d" % seed
     env.close()
     if osc.last_spins:
         # a CSG stream the reference never finishes computing (shape.rs:390-392 under an outer operation that keeps asking, e.g.
@@ -43,8 +50,31 @@ def run_case(seed, w, h, depth, time_ms=0, n_entities=None, min_flat_bytes=0):
     assert diff.size == 0, "seed %d: %d differing bytes, first at %s: gpu %s oracle %s" % (
         seed, len(diff), diff[0], img.data[tuple(diff[0][:2])], orgb[tuple(diff[0][:2])])
     assert img.stats == ost, (seed, img.stats, ost)
-    both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
-    assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan]), seed
+    gh = img.hit_t.astype(np.float32) if low_precision else img.hit_t
+    both_nan = np.isnan(gh) & np.isnan(ohit)
+    assert np.array_equal(gh[~both_nan], ohit[~both_nan]), seed
+
+
+@pytest.mark.interpreter_only
+@pytest.mark.parametrize("chunk", range(20))
+def test_random_scene_hunt_f64(chunk):
+    """2 000 random scenes per run (seeds 40000 + 100 * chunk ...), small frames: the hunt that used to live in tools/ only."""
+    for seed in range(40000 + 100 * chunk, 40000 + 100 * (chunk + 1)):
+        try:
+            run_case(seed, 40, 30, 5, time_ms=250 * (seed % 5))
+        except pytest.skip.Exception:
+            continue
+
+
+@pytest.mark.interpreter_only
+@pytest.mark.parametrize("chunk", range(6))
+def test_random_scene_hunt_f32(chunk):
+    """600 more on the F = f32 pair (libeuclider_amd_f32.so against libeo_oracle_f32.so)."""
+    for seed in range(60000 + 100 * chunk, 60000 + 100 * (chunk + 1)):
+        try:
+            run_case(seed, 40, 30, 5, low_precision=True)
+        except pytest.skip.Exception:
+            continue
 
 
 @pytest.mark.parametrize("seed", range(0, 120))
@@ -63,6 +93,7 @@ def test_random_scene_parity_deeper_and_larger(seed):
     run_case(seed, 160, 90, 8)
 
 
+@pytest.mark.interpreter_only
 @pytest.mark.parametrize("seed", range(300, 340))
 def test_random_scene_trace_path(seed):
     """Camera motion (Universe::trace_path_unknown) through random scenes: GPU == oracle, bit for bit."""
