@@ -527,6 +527,7 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
     const uint32_t cap = h.hit_cap < 8 ? 8u : ((h.hit_cap + 3u) & ~3u);
     plan.hs_lds = h.hit_cap <= 32;
     plan.hs_cap = cap;
+    plan.too_large = h.n_ops > kJitMaxShapeOps || h.n_entities > kJitMaxEntities;
     Gen g(flat);
     g.generate();
     Out tail;
@@ -594,6 +595,11 @@ static std::string library_cache_dir() {      /* <directory of this shared libra
 }
 
 int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out) {
+    if (plan.too_large) {
+        out.log = "the scene is too large to specialise (more than " + std::to_string(kJitMaxShapeOps) + " shape operations or " + std::to_string(kJitMaxEntities) +
+                  " entities): the interpreter kernels trace it";
+        return EU_ERR_CAPACITY;
+    }
 #if EU_REAL_BITS == 32
     const std::string fname = plan.key + "_f32.hsaco";
 #else

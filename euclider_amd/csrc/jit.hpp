@@ -27,7 +27,13 @@ struct JitPlan {
     std::string source;          /* HIP source of the translation unit */
     std::vector<std::string> extra_flags;      /* caller's tuning flags (eu_renderer_opts.jit_flags), part of the key */
     std::string key;             /* hex digest of everything the code object depends on */
+    bool too_large = false;      /* the scene has more shape ops / entities than straight-line code is worth compiling for (jit_build refuses) */
 };
+
+/* Straight-line code for every entity compiles in time that grows faster than the scene (3d_room: 10 shape ops, 6 s; 4d_cylinders: 248
+ * ops, 38 s; a random scene of 266 ops: 166 s; 600 ops: more than ten minutes): beyond these limits a renderer keeps the interpreter
+ * kernels (eu_jit_info.active = 0). */
+constexpr uint32_t kJitMaxShapeOps = 256, kJitMaxEntities = 48;
 
 /* Pure host code (no HIP call): the specialised translation unit for this scene. */
 JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags = std::string());

@@ -6,7 +6,9 @@ dev = torch.device("cuda", 0)
 n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 scene = sys.argv[2] if len(sys.argv) > 2 else "3d_room.json"
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-envs = [Parser().parse_file("scenes/" + scene) for _ in range(n_env)]
+spec = sys.argv[4] if len(sys.argv) > 4 else "sync"
+n_streams = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+envs = [Parser().parse_file("scenes/" + scene).configure(specialize=spec, streams=n_streams) for _ in range(n_env)]
 for e in envs: e.camera.max_depth = depth
 W, H = 1920, 1080
 streams = [torch.cuda.Stream(dev) for _ in range(n_env)]
@@ -25,5 +27,5 @@ for k in range(K): step(k)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 rays = envs[0].stats()["rays"]
-print(scene, depth, "kernel", os.environ.get("EU_KERNEL", "wavefront"), "envs", n_env, "streams env", os.environ.get("EU_WF_STREAMS"), "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
+print(scene, depth, "specialize", spec, "renderers in flight", n_env, "band streams", n_streams or "default", "ms/frame %.3f" % (dt / K * 1e3), "Mray/s %.1f" % (rays * K / dt / 1e6))
 assert torch.equal(rgb[0][:H*W*3], rgb[-1][:H*W*3])
