@@ -58,6 +58,7 @@ def parse_args():
                          "region; off: the ahead-of-time kernels that interpret the flat scene")
     ap.add_argument("--streams", type=int, default=0, help="band pipelines in flight per frame (0 = the library's default)")
     ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
+    ap.add_argument("--renderer-flags", type=int, default=0, help="eu_renderer_opts.flags")
     return ap.parse_args()
 
 
@@ -257,7 +258,7 @@ def other_configs(torch, dev, stream, Parser, args):
                                           ("4d_cylinders.json", 1920, 1080, 8, 8, False), ("3d_room.json", 7680, 4320, 8, 3, False),
                                           ("3d_room.json", 1920, 1080, 10, 12, False), ("3d_room.json", 1920, 1080, 8, 12, True)):
         env = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
-        env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags)
+        env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
         env.camera.max_depth = depth
         frame = env.frame(W, H, time=0.0, rows=(0, H))
         rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -326,7 +327,7 @@ def main():
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
     env = Parser(low_precision=args.low_precision).parse_file(scene_path)
-    env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags)
+    env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
     env.camera.max_depth = args.max_depth
     jit = env.jit_info(device=local_rank)      # (creates the renderer: a specialised one compiles or fetches its kernels here, before any timing)
     if args.specialize == "sync" and not jit["active"]:

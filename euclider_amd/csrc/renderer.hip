@@ -109,6 +109,8 @@ struct eu_renderer {
     bool prepare_only = false;               /* render_device_impl: size the work buffers for the frame, launch nothing */
     hipStream_t wf_stream[WF_MAX_STREAMS] = {};
     hipEvent_t wf_fork = nullptr, wf_join[WF_MAX_STREAMS] = {};
+    uint32_t wf_seg_per_cu = 3;              /* producer (shade) workgroups per CU = queue segments per CU: 3 for the interpreter's shade kernel (168 VGPRs),
+                                              * what the specialised one's registers allow (up to 4) */
     int wf_n_streams = 2;
     real wf_ray_factor = R(4.0);
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass */
@@ -167,6 +169,12 @@ static void renderer_attach_jit(eu_renderer *r) {
     r->jit_hs_lds = plan.hs_lds;
     r->jit_hs_cap = plan.hs_cap;
     r->jit.active = 1;
+    int occ = 0, occ0 = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, r->jit_shade, EU_WF_BLOCK, 0) == hipSuccess &&
+        hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, r->jit_shade0, EU_WF_BLOCK, 0) == hipSuccess) {
+        const int o = occ < occ0 ? occ : occ0;
+        r->wf_seg_per_cu = o >= 4 ? 4u : (o >= 3 ? 3u : (o >= 2 ? 2u : 1u));
+    } else (void)hipGetLastError();
 }
 
 static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_scene, int device, const eu_renderer_opts *opts_in, eu_renderer **out, char *err, size_t errlen) {
@@ -335,7 +343,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_d
     EuWfBuffers &B = r->wf[set];
     memset(&B, 0, sizeof B);
     /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
-    uint32_t n_seg = (uint32_t)r->num_cus * 3u;
+    uint32_t n_seg = (uint32_t)r->num_cus * r->wf_seg_per_cu;
     if (n_seg > EU_WF_MAX_SEG) n_seg = EU_WF_MAX_SEG;
     if (pixels / 16 < n_seg) n_seg = pixels / 16 < 16 ? 16u : (uint32_t)(pixels / 16);      /* tiny frames, single pixels: fewer producers, small buffers */
     size_t seg_cap = ((size_t)((real)pixels * r->wf_ray_factor) + n_seg - 1) / n_seg;
@@ -368,6 +376,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_d
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
     }
+
     if (!r->wf_stream[0]) {
         for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) { HIP_TRY(hipStreamCreateWithFlags(&r->wf_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&r->wf_join[k], hipEventDisableTiming)); }
         HIP_TRY(hipEventCreateWithFlags(&r->wf_fork, hipEventDisableTiming));
@@ -431,7 +440,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     else if (hs_small) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 16>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 16>, 0, g_isect0))) return rc; }
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 96>, 0, g_isect0))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 0>, isect_lds, g_isect0))) return rc;
-    if ((rc = wf_grid(r, eu_wf_resolve_kernel, 0, g_res))) return rc;
+    g_res = (unsigned)r->wf[0].n_seg;      /* one workgroup per queue segment */
     if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
         for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));

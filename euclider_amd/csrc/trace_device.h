@@ -56,7 +56,7 @@ struct EuDevCounters {      /* device memory, zeroed before each launch */
     unsigned long long phase[16];  /* diagnostic builds only */
     unsigned long long gen_count[EU_MAX_DEPTH + 2];   /* wavefront pipeline: rays queued per generation */
     unsigned long long overflow;                      /* rays / nodes dropped because a queue was full */
-    unsigned long long node_chunks;                   /* stream kernel: node chunks handed out so far */
+    unsigned long long node_chunks;                   /* (unused) */
 };
 
 /* ------------------------------------------------------------------ scene view */

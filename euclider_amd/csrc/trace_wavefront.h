@@ -422,8 +422,11 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
         /* a generation too small to give every workgroup a full window is cut into smaller ones: a window's rays are
          * shaded EU_WF_BLOCK at a time, so its latency (the kernel's critical path) shrinks with it */
         const uint32_t win = total > gridDim.x * (EU_WF_WIN / 2) ? EU_WF_WIN : (total > gridDim.x * (EU_WF_WIN / 4) ? EU_WF_WIN / 2 : EU_WF_WIN / 4);
+        /* (Round 3 measured a dynamic deal of the windows through one counter per launch: equal at best -- 6211 vs 6219 Mray/s on 3d_room --
+         * and 12 % slower on 3d_hallways when every workgroup's first window came from the counter too: 768 workgroups asking one address
+         * at the same moment at the start of every launch.) */
         const uint32_t stride = gridDim.x * win;
-        const uint32_t iters = (total + stride - 1) / stride;             /* whole iterations: block-wide append below */
+        const uint32_t iters = (total + stride - 1) / stride;
         for (uint32_t it = 0; it < iters; it++) {
             const uint32_t wbase = it * stride + blockIdx.x * win;
             if (threadIdx.x < EU_WF_KEYS) hist[threadIdx.x] = 0;
@@ -618,31 +621,33 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kern
 
 /* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes
  * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
- * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass */
-EU_DEV void wf_resolve_generation(uint32_t gen, uint32_t total0, const EuWfBuffers &B, LaneCounters &cnt, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb,
-                                  uint32_t *pref, uint32_t *wave_tot) {
-    const uint32_t node_base = gen * B.ray_cap;
-    const bool g0 = gen == 0;
-    const uint32_t total = g0 ? total0 : wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
-        const uint32_t nid = node_base + (g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v));
-        const uint32_t kind = B.node_kind[nid];
-        if (kind == TS_NONE) continue;
-        const EuTsNode *N = B.nodes + nid;
-        Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
-        if (kind != TS_COMBINE_INTER) {
-            const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
-            res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
-        }
-        ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
-    }
-}
-
+ * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass.
+ * A workgroup walks whole queue segments (segment s: slots s * seg_cap ... + count[s]): no prefix table, no index search; the work
+ * per slot is one byte read unless the ray left a node, so uneven segments do not matter.
+ * (Round 3 also measured all generations in ONE launch with a grid-wide barrier between them -- release / acquire fences at device
+ * scope around a counter: 4.8 instead of 6.2 Gray/s on 3d_room.  Each fence writes back and invalidates the XCD's L2, which at that
+ * moment holds the other band pipeline's ray queues.) */
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, uint32_t total0, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
     LaneCounters cnt = {0, 0, 0, 0};
-    __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
-    __shared__ uint32_t wave_tot[4];
-    wf_resolve_generation(gen, total0, B, cnt, rgba, point_rgb, pref, wave_tot);
+    const uint32_t node_base = gen * B.ray_cap;
+    const bool g0 = gen == 0;
+    const uint32_t n_units = g0 ? (total0 + EU_WF_WIN - 1) / EU_WF_WIN : B.n_seg;      /* generation 0 has no segments: units of EU_WF_WIN items */
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t first = g0 ? u * EU_WF_WIN : u * B.seg_cap;
+        const uint32_t count = g0 ? (total0 - first < EU_WF_WIN ? total0 - first : EU_WF_WIN) : B.seg_count[gen * B.n_seg + u];
+        for (uint32_t k = threadIdx.x; k < count; k += EU_WF_BLOCK) {
+            const uint32_t nid = node_base + first + k;
+            const uint32_t kind = B.node_kind[nid];
+            if (kind == TS_NONE) continue;
+            const EuTsNode *N = B.nodes + nid;
+            Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
+            if (kind != TS_COMBINE_INTER) {
+                const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
+                res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
+            }
+            ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
+        }
+    }
     wf_flush_counters(counters, cnt);
 }
 

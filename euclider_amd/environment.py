@@ -101,11 +101,11 @@ class Environment:
     #               with hiprtc when the renderer is created, a few seconds the first time, cached on disk), None = the library default
     #   kernel: None / "wavefront" / "stack";  streams, ray_factor, band_pixels: 0 = default;  shade_scene_global: test hook
     def configure(self, specialize=None, kernel=None, streams=0, ray_factor=0.0, band_pixels=0, cache_dir=None, shade_scene_global=False,
-                  jit_flags=None):
+                  jit_flags=None, flags=0):
         if self._renderers:
             raise RuntimeError("configure() before the first renderer exists")
         self._opts = dict(specialize=specialize, kernel=kernel, streams=streams, ray_factor=ray_factor, band_pixels=band_pixels,
-                          cache_dir=cache_dir, shade_scene_global=shade_scene_global, jit_flags=jit_flags)
+                          cache_dir=cache_dir, shade_scene_global=shade_scene_global, jit_flags=jit_flags, flags=flags)
         return self
 
     def _renderer_opts(self):
@@ -117,7 +117,7 @@ class Environment:
         flags = o.get("jit_flags")
         return _capi.RendererOpts(C.sizeof(_capi.RendererOpts), kern, spec, int(o.get("streams") or 0), float(o.get("ray_factor") or 0.0),
                                   int(o.get("band_pixels") or 0), cache.encode() if cache else None,
-                                  _capi.EU_RENDERER_SHADE_SCENE_GLOBAL if o.get("shade_scene_global") else 0, 0,
+                                  (_capi.EU_RENDERER_SHADE_SCENE_GLOBAL if o.get("shade_scene_global") else 0) | int(o.get("flags") or 0), 0,
                                   flags.encode() if flags else None)
 
     def renderer(self, device=0):
