@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0, help="band pipelines in flight per frame (0 = the library's default)")
     ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
     ap.add_argument("--renderer-flags", type=int, default=0, help="eu_renderer_opts.flags")
+    ap.add_argument("--abi-child", type=int, default=0,
+                    help="internal: ONE process drives this many GPUs through the C ABI (eu_render_multi) on the 8K frame and prints a JSON object")
     return ap.parse_args()
 
 
@@ -237,6 +239,26 @@ def animate(args, env, scene_path):
     print(json.dumps(out), flush=True)
 
 
+def abi_child(args):
+    """BASELINE config 5 through the C ABI: one process, eu_multi over N devices (what a Rust `impl Environment` would call).  Runs in a
+    process of its own, started by rank 0 of the per-process run after its own measurements."""
+    from euclider_amd import Parser
+    n = args.abi_child
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", args.scene)).configure(specialize=args.specialize)
+    env.camera.max_depth = args.max_depth
+    W, H = 7680, 4320
+    img = env.render_multi((W, H), list(range(n)))      # warm-up: renderers, kernels, buffers
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img = env.render_multi((W, H), list(range(n)))
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"workload": "%s %dx%d depth %d, ONE process, eu_render_multi over %d devices (host image included)" % (args.scene, W, H, args.max_depth, n),
+                      "value": img.stats["rays"] / dt / 1e6, "unit": "Mray/s", "ms_per_step": dt * 1e3, "steps": steps, "rays_per_frame": int(img.stats["rays"]),
+                      "note": "synchronous call: traces, gathers over xGMI (peer copies), restores row order and copies the 99.5 MB image to the host"}), flush=True)
+    env.close()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (before anything here
     has touched the GPU) and leave with its exit code."""
@@ -295,6 +317,9 @@ def other_configs(torch, dev, stream, Parser, args):
 
 def main():
     args = parse_args()
+    if args.abi_child:
+        abi_child(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -415,13 +440,24 @@ def main():
     tot = [run["rays"], 0.0, run["panic"]]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    cfg5 = None
+    cfg5 = cfg5_abi = None
     if world > 1 and not args.fixed_frame:      # BASELINE config 5 next to the weak-scaling value: the 8K frame over the same ranks (strong scaling)
         r5 = timed_run(7680, 4320, 3, 1)
         cfg5 = {"workload": "%s 7680x4320 depth %d, %d ranks" % (args.scene, args.max_depth, world), "scaling": "strong",
                 "value": r5["rays"] * r5["steps"] / r5["elapsed"] / 1e6, "unit": "Mray/s", "ms_per_step": r5["elapsed"] / r5["steps"] * 1e3,
                 "steps": r5["steps"], "rays_per_frame": int(r5["rays"])}
         del r5
+        if rank == 0 and not smoke_gloo:      # the same frame through the C ABI's one-process path, in a process of its own (the other ranks wait at the next barrier)
+            import subprocess
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--abi-child", str(world), "--scene", args.scene, "--max-depth", str(args.max_depth),
+                                     "--specialize", args.specialize], capture_output=True, text=True, timeout=240,
+                                    env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")})
+                cfg5_abi = json.loads(cp.stdout.strip().split("\n")[-1]) if cp.returncode == 0 else {"error": (cp.stderr or cp.stdout)[-400:]}
+            except Exception as e:      # never let the extra measurement take the line down
+                cfg5_abi = {"error": repr(e)[:400]}
+        if world > 1:
+            dist.barrier()
     if rank == 0 and os.environ.get("EU_BENCH_DUMP"):
         import numpy as np
         np.save(os.environ["EU_BENCH_DUMP"], rgb_out[:H * W * 3].cpu().numpy().reshape(H, W, 3))
@@ -451,6 +487,8 @@ def main():
         }
         if cfg5 is not None:
             out["config5"] = cfg5
+        if cfg5_abi is not None:
+            out["config5_abi"] = cfg5_abi
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
             cb, orgb, rows, ost = cpu_baseline(scene_path, W, H, args.max_depth, args.cpu_sample_rows, "f32" if args.low_precision else "")

@@ -175,7 +175,10 @@ def lib(low_precision=False):
                               "there is no fallback implementation" % LIB_PATH)
         _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
+        host_only = os.environ.get("EU_LIB_HOST_ONLY") == "1"      # the sanitizer build (csrc/Makefile `asan`) holds the host side only
         for name, (res, args) in SYMBOLS.items():
+            if host_only and not hasattr(L, name):
+                continue
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args

@@ -63,7 +63,8 @@ def dvec32(vals, n=4):
 
 
 _libs = {}
-VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so", "f32": "libeo_oracle_f32.so"}
+VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so", "f32": "libeo_oracle_f32.so",
+            "asan": "libeo_oracle_asan.so"}
 
 
 def build(force=False, variant=""):

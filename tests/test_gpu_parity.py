@@ -154,9 +154,10 @@ def test_full_size_properties_config1():
     assert a.stats["nan_pixels"] == ost["nan_pixels"] and a.stats["errors"] == ost["errors"]
 
 
-@pytest.mark.parametrize("scene,depth", [("3d_hallways.json", 12), ("4d_frame.json", 8)])
+@pytest.mark.parametrize("scene,depth", [("3d_hallways.json", 12), ("4d_frame.json", 8), ("4d_cylinders.json", 8), ("3d_room.json", 10)])
 def test_full_size_whole_frame_other_configs(scene, depth):
-    """configs[2] and configs[3] at 1920x1080: the whole frame and the counters against the oracle + partition invariance."""
+    """configs[2] and configs[3] at 1920x1080, the README's "cylinder hypercube" and 3d_room at the reference's own depth
+    (d3/entity/camera.rs:50): the whole frame and the counters against the oracle + partition invariance."""
     from euclider_amd import Parser
     from oracle.scene_loader import load_scene_file
     path = os.path.join(SCENES, scene)
