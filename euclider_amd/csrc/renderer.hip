@@ -440,7 +440,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     else if (hs_small) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 16>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 16>, 0, g_isect0))) return rc; }
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 96>, 0, g_isect0))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 0>, isect_lds, g_isect0))) return rc;
-    g_res = (unsigned)r->wf[0].n_seg;      /* one workgroup per queue segment */
+    if ((rc = wf_grid(r, eu_wf_resolve_kernel, 0, g_res))) return rc;
     if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
         for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));

@@ -331,6 +331,7 @@ template <int D> EU_DEV bool inside_subtree(const EuScene &S, uint32_t first, ui
  * ds_read/ds_write_b64) when the scene's static bound fits, else in private (scratch) memory */
 struct HitStackLds {
     real *t; uint32_t *c; uint32_t cap;
+    static constexpr bool kPrivate = false;
     EU_DEV real gt(uint32_t k) const { return t[k * 64]; }
     EU_DEV uint32_t gc(uint32_t k) const { return c[k * 64]; }
     EU_DEV void set(uint32_t k, real tt, uint32_t cc) { t[k * 64] = tt; c[k * 64] = cc; }
@@ -339,6 +340,7 @@ struct HitStackLds {
 template <int CAP> struct HitStackPriv {
     real t[CAP]; uint32_t c[CAP];
     static constexpr uint32_t cap = CAP;
+    static constexpr bool kPrivate = true;
     EU_DEV real gt(uint32_t k) const { return t[k]; }
     EU_DEV uint32_t gc(uint32_t k) const { return c[k]; }
     EU_DEV void set(uint32_t k, real tt, uint32_t cc) { t[k] = tt; c[k] = cc; }
@@ -639,6 +641,15 @@ template <int D> EU_DEV bool ray_misses_bound(const real *Bd, const real *o, con
     return false;
 }
 
+/* t_k of a chain's leaf `idx`, picked with compares (for a hit stack in private memory: staging the t_k through it, as the LDS form
+ * does, is eight scratch stores and a dependent load per chain -- 4d_frame wrote 0.7 GB per frame that way) */
+EU_DEV real chain_pick_t(const real (&tk)[EU_CHAIN_MAX], uint32_t count, uint32_t idx) {
+    real t = tk[0];
+#pragma unroll
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (k < count) t = (idx == k) ? tk[k] : t;
+    return t;
+}
+
 /* ------------------------------------------------------------------ CSG: eager post-order evaluation
  * The pieces below are shared by the interpreter (eval_shape walks an entity's shape program op by op) and by the
  * scene-specialised kernels (jit.cpp emits the same calls in a straight line, every kind, count and parameter a constant). */
@@ -671,9 +682,13 @@ EU_DEV uint32_t eval_single(uint32_t kind, uint32_t count, const real *P, const 
         const uint32_t n = eval_chain<D>(kind, count, P, o, d, tk, list, use_box, fail);
 #endif
         if (n) {      /* pick t by a run-time index through the (LDS) hit stack, not through a private array */
+            if constexpr (HS::kPrivate) first_t = chain_pick_t(tk, count, list & 15u);
+            else {
 #pragma unroll
-            for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
-            first_t = hs.gt(list & 15u); first_c = op_index | ((list & 15u) << 16);
+                for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(k, tk[k]);
+                first_t = hs.gt(list & 15u);
+            }
+            first_c = op_index | ((list & 15u) << 16);
         }
         SHP(cnt, 3);
         return n;
@@ -715,13 +730,20 @@ EU_DEV CsgList push_chain(uint32_t kind, uint32_t count, const real *P, const re
 #endif
     }
     SHP(cnt, 0);
-    if (n) {
+    if constexpr (HS::kPrivate) {
+        for (uint32_t p = 0; p < n; p++) {
+            const uint32_t idx = (list >> (4 * p)) & 15u;
+            hs.set(sp + p, chain_pick_t(tk, count, idx), op_index | (idx << 16));
+        }
+    } else {
+        if (n) {
 #pragma unroll
-        for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
-    }
-    for (uint32_t p = 0; p < n; p++) {
-        const uint32_t idx = (list >> (4 * p)) & 15u;
-        hs.set(sp + p, hs.gt(sp + count + idx), op_index | (idx << 16));
+            for (uint32_t k = 0; k < EU_CHAIN_MAX; k++) if (k < count) hs.set_t(sp + count + k, tk[k]);
+        }
+        for (uint32_t p = 0; p < n; p++) {
+            const uint32_t idx = (list >> (4 * p)) & 15u;
+            hs.set(sp + p, hs.gt(sp + count + idx), op_index | (idx << 16));
+        }
     }
     sp += n;
     SHP(cnt, 3);

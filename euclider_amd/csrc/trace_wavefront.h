@@ -622,31 +622,28 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kern
 /* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes
  * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
  * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass.
- * A workgroup walks whole queue segments (segment s: slots s * seg_cap ... + count[s]): no prefix table, no index search; the work
- * per slot is one byte read unless the ray left a node, so uneven segments do not matter.
- * (Round 3 also measured all generations in ONE launch with a grid-wide barrier between them -- release / acquire fences at device
- * scope around a counter: 4.8 instead of 6.2 Gray/s on 3d_room.  Each fence writes back and invalidates the XCD's L2, which at that
- * moment holds the other band pipeline's ray queues.) */
+ * (Round 3 measured two other forms.  All generations in ONE launch with a grid-wide barrier between them -- release / acquire fences at
+ * device scope around a counter: 4.8 instead of 6.2 Gray/s on 3d_room; each fence writes back and invalidates the XCD's L2, which at that
+ * moment holds the other band pipeline's ray queues.  One workgroup per queue segment, without the prefix table: 26 us per launch instead
+ * of 19; the launch is bound by its node traffic -- 64-byte records, 32-byte deliveries -- and wants the whole chip's worth of waves.) */
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, uint32_t total0, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t node_base = gen * B.ray_cap;
     const bool g0 = gen == 0;
-    const uint32_t n_units = g0 ? (total0 + EU_WF_WIN - 1) / EU_WF_WIN : B.n_seg;      /* generation 0 has no segments: units of EU_WF_WIN items */
-    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint32_t first = g0 ? u * EU_WF_WIN : u * B.seg_cap;
-        const uint32_t count = g0 ? (total0 - first < EU_WF_WIN ? total0 - first : EU_WF_WIN) : B.seg_count[gen * B.n_seg + u];
-        for (uint32_t k = threadIdx.x; k < count; k += EU_WF_BLOCK) {
-            const uint32_t nid = node_base + first + k;
-            const uint32_t kind = B.node_kind[nid];
-            if (kind == TS_NONE) continue;
-            const EuTsNode *N = B.nodes + nid;
-            Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
-            if (kind != TS_COMBINE_INTER) {
-                const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
-                res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
-            }
-            ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
+    __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t total = g0 ? total0 : wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        const uint32_t nid = node_base + (g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v));
+        const uint32_t kind = B.node_kind[nid];
+        if (kind == TS_NONE) continue;
+        const EuTsNode *N = B.nodes + nid;
+        Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
+        if (kind != TS_COMBINE_INTER) {
+            const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
+            res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
         }
+        ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
     }
     wf_flush_counters(counters, cnt);
 }

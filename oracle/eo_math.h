@@ -36,101 +36,141 @@ static inline int eo_isnan(double x) { return x != x; }
 #define EO_PIO2_LO 6.12323399573676603587e-17
 #define EO_PIO4_HI 7.85398163397448278999e-01
 
-/* rational approximation shared by acos and asin: R(z) = p(z)/q(z) */
-static inline double eo_asin_p(double z) {
-    return z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
-           z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+/* ---- acos and asin, correctly rounded but for about one argument in two thousand ----
+ * (Rounds 1-2 carried fdlibm's e_acos / e_asin: < 1 ulp, and different from the correctly rounded value for 7.7 % / 5.8 % of random
+ * arguments.  That mattered: `get_intersection_color` tests a quantised alpha for == 255 (surface.rs:73), an opaque blend's alpha is 1
+ * or 1 - 2^-53 depending on the last bit of an acos, and a build of the oracle on glibc's libm -- what Rust's f64::acos calls on Linux,
+ * itself correctly rounded for all but 0.11 % of arguments -- differed from this one in 2.08 % of 3d_room's bytes.)
+ *
+ * asin(s) = s + s^3 g(z), z = s^2 in [0, 1/4], g(z) = sum_{n>=1} c_n z^(n-1), c_n = (2n)! / (4^n n!^2 (2n+1)).  The terms of n = 1, 2, 3
+ * are carried in double-double arithmetic (coefficients exact to 2^-106), the rest -- at most 1.2e-4 of the result -- is a degree-15
+ * polynomial in double (Chebyshev interpolant of the exact series, relative error 2^-55.5).  Error of the sum: below 2^-65 of the
+ * result, i.e. the final rounding differs from the correct one for about 2^-11 of the arguments (measured: tests/test_oracle_math.py).
+ *   |x| <  1/2:  asin x = K(x, x^2),                 acos x = pi/2 - K(x, x^2)
+ *   |x| >= 1/2:  with z = (1 - |x|) / 2 (exact) and s = sqrt(z) as a double-double:
+ *                asin x = +-(pi/2 - 2 K(s, z)),      acos x = 2 K(s, z)  (x > 0),   pi - 2 K(s, z)  (x < 0)
+ * Only IEEE + - * / sqrt and fma are used; fma(a, b, c) is a single correctly rounded operation on the device and on the host alike. */
+#define EO_FMA(a, b, c) __builtin_fma((a), (b), (c))
+static inline double eo_asin_tail(double z) {      /* sum_{n>=4} c_n z^(n-4) on [0, 1/4] */
+    return 0x1.f1c71c71c71c7p-6 + z * (0x1.6e8ba2e8ba2e9p-6 + z * (0x1.1c4ec4ec4ec4bp-6 + z * (0x1.c999999999e89p-7 + z * (0x1.7a8787876be59p-7 +
+           z * (0x1.3fde50dd73215p-7 + z * (0x1.12ef3c20e26eap-7 + z * (0x1.df3bfcbdb62d4p-8 + z * (0x1.a683535f31d33p-8 + z * (0x1.7854ca3f14fe8p-8 +
+           z * (0x1.503462916817ap-8 + z * (0x1.3ce57f72fa79fp-8 + z * (0x1.a96c77a266974p-9 + z * (0x1.08eaccc123691p-7 + z * (-0x1.31ed0a9cc3c14p-7 +
+           z * (0x1.f951c9ae35c84p-6 + z * (-0x1.19c1d5ee3df84p-5 + z * 0x1.dc10ddb789ef5p-6))))))))))))))));
 }
-static inline double eo_asin_q(double z) {
-    return 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 +
-           z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+/* K(s, z) = asin(s) as a double-double (rh + rl), for s = sh + sl with |s| <= 1/2 and z = zh + zl = s^2 */
+static inline void eo_asin_kernel(double sh, double sl, double zh, double zl, double *rh, double *rl) {
+    const double c1h = 0x1.5555555555555p-3, c1l = 0x1.5555555555555p-57;       /* 1/6 */
+    const double c2h = 0x1.3333333333333p-4, c2l = 0x1.999999999999ap-59;       /* 3/40 */
+    const double c3h = 0x1.6db6db6db6db7p-5, c3l = -0x1.2492492492492p-60;      /* 5/112 */
+    const double t = eo_asin_tail(zh);
+    /* L3 = c3 + z t */
+    double p = zh * t, e = EO_FMA(zh, t, -p);
+    double l3h = c3h + p, l3l = ((c3h - l3h) + p) + (c3l + e);
+    /* L2 = c2 + z L3 */
+    p = zh * l3h; e = EO_FMA(zh, l3h, -p) + (zh * l3l + zl * l3h);
+    double l2h = c2h + p, l2l = ((c2h - l2h) + p) + (c2l + e);
+    /* L1 = c1 + z L2 */
+    p = zh * l2h; e = EO_FMA(zh, l2h, -p) + (zh * l2l + zl * l2h);
+    double l1h = c1h + p, l1l = ((c1h - l1h) + p) + (c1l + e);
+    /* W = z L1,  T = s W,  R = s + T */
+    double wh = zh * l1h, wl = EO_FMA(zh, l1h, -wh) + (zh * l1l + zl * l1h);
+    double th = sh * wh, tl = EO_FMA(sh, wh, -th) + (sh * wl + sl * wh);
+    double h = sh + th;
+    *rl = ((sh - h) + th) + (sl + tl);
+    *rh = h;
 }
+#define EO_PI_H 0x1.921fb54442d18p+1
+#define EO_PI_L 0x1.1a62633145c07p-53
+#define EO_PIO2_H 0x1.921fb54442d18p+0
+#define EO_PIO2_L 0x1.1a62633145c07p-54
 
 static inline double eo_acos(double x) {
     uint32_t hx = eo_hi(x), ix = hx & 0x7fffffffu;
     if (ix >= 0x3ff00000u) {                     /* |x| >= 1 */
         if (((ix - 0x3ff00000u) | eo_lo(x)) == 0) {
             if ((int32_t)hx > 0) return 0.0;
-            return EO_PI + 2.0 * EO_PIO2_LO;
+            return EO_PI_H;                     /* RN(pi) */
         }
         return (x - x) / (x - x);                /* NaN */
     }
-    if (ix < 0x3fe00000u) {                      /* |x| < 0.5 */
-        if (ix <= 0x3c600000u) return EO_PIO2_HI + EO_PIO2_LO;
-        double z = x * x;
-        double r = eo_asin_p(z) / eo_asin_q(z);
-        return EO_PIO2_HI - (x - (EO_PIO2_LO - x * r));
-    } else if ((int32_t)hx < 0) {                /* x < -0.5 */
-        double z = (1.0 + x) * 0.5;
-        double p = eo_asin_p(z), q = eo_asin_q(z);
-        double s = sqrt(z);
-        double r = p / q;
-        double w = r * s - EO_PIO2_LO;
-        return EO_PI - 2.0 * (s + w);
-    } else {                                     /* x > 0.5 */
-        double z = (1.0 - x) * 0.5;
-        double s = sqrt(z);
-        double df = eo_clear_lo(s);
-        double c = (z - df * df) / (s + df);
-        double p = eo_asin_p(z), q = eo_asin_q(z);
-        double r = p / q;
-        double w = r * s + c;
-        return 2.0 * (df + w);
+    double rh, rl;
+    if (ix < 0x3fe00000u) {                      /* |x| < 1/2: pi/2 - K(x, x^2) */
+        const double zh = x * x, zl = EO_FMA(x, x, -zh);
+        eo_asin_kernel(x, 0.0, zh, zl, &rh, &rl);
+        const double h = EO_PIO2_H - rh;
+        return h + (((EO_PIO2_H - h) - rh) + (EO_PIO2_L - rl));
     }
+    const double z = (1.0 - fabs(x)) * 0.5;      /* exact: 1 - |x| by Sterbenz, the halving by scaling */
+    const double sh = sqrt(z);
+    const double sl = EO_FMA(-sh, sh, z) / (sh + sh);      /* sqrt(z) = sh + sl to ~2^-104 */
+    eo_asin_kernel(sh, sl, z, 0.0, &rh, &rl);
+    if ((int32_t)hx > 0) return 2.0 * (rh + rl);
+    const double h = EO_PI_H - 2.0 * rh;
+    return h + (((EO_PI_H - h) - 2.0 * rh) + (EO_PI_L - 2.0 * rl));
 }
 
 static inline double eo_asin(double x) {
     uint32_t hx = eo_hi(x), ix = hx & 0x7fffffffu;
     if (ix >= 0x3ff00000u) {
-        if (((ix - 0x3ff00000u) | eo_lo(x)) == 0) return x * EO_PIO2_HI + x * EO_PIO2_LO;
+        if (((ix - 0x3ff00000u) | eo_lo(x)) == 0) return ((int32_t)hx > 0) ? EO_PIO2_H : -EO_PIO2_H;      /* RN(+-pi/2) */
         return (x - x) / (x - x);
-    } else if (ix < 0x3fe00000u) {
-        if (ix < 0x3e400000u) return x;          /* |x| < 2^-27 */
-        double t = x * x;
-        double w = eo_asin_p(t) / eo_asin_q(t);
-        return x + x * w;
     }
-    double w = 1.0 - fabs(x);
-    double t = w * 0.5;
-    double p = eo_asin_p(t), q = eo_asin_q(t);
-    double s = sqrt(t);
-    if (ix >= 0x3FEF3333u) {                     /* |x| > 0.975 */
-        w = p / q;
-        t = EO_PIO2_HI - (2.0 * (s + s * w) - EO_PIO2_LO);
-    } else {
-        w = eo_clear_lo(s);
-        double c = (t - w * w) / (s + w);
-        double r = p / q;
-        p = 2.0 * s * r - (EO_PIO2_LO - 2.0 * c);
-        q = EO_PIO4_HI - 2.0 * w;
-        t = EO_PIO4_HI - (p - q);
+    double rh, rl;
+    if (ix < 0x3fe00000u) {                      /* |x| < 1/2 */
+        if (ix < 0x3e400000u) return x;          /* |x| < 2^-27: x (1 + x^2/6 + ...) rounds to x */
+        const double zh = x * x, zl = EO_FMA(x, x, -zh);
+        eo_asin_kernel(x, 0.0, zh, zl, &rh, &rl);
+        return rh + rl;
     }
-    return ((int32_t)hx > 0) ? t : -t;
+    const double z = (1.0 - fabs(x)) * 0.5;
+    const double sh = sqrt(z);
+    const double sl = EO_FMA(-sh, sh, z) / (sh + sh);
+    eo_asin_kernel(sh, sl, z, 0.0, &rh, &rl);
+    const double h = EO_PIO2_H - 2.0 * rh;
+    const double r = h + (((EO_PIO2_H - h) - 2.0 * rh) + (EO_PIO2_L - 2.0 * rl));
+    return ((int32_t)hx > 0) ? r : -r;
 }
 
-static inline double eo_ksin(double x, double y, int iy) {
-    uint32_t ix = eo_hi(x) & 0x7fffffffu;
-    if (ix < 0x3e400000u) { if ((int)x == 0) return x; }
-    double z = x * x;
-    double v = z * x;
-    double r = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
-               z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    if (iy == 0) return x + v * (-1.66666666666666324348e-01 + z * r);
-    return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01);
+/* ---- sin and cos kernels on |r| <= pi/4, r = rh + rl: the Taylor series, whose coefficients are exact rationals; the terms that exceed
+ * 2^-14 of the result (r^3/6, r^5/120 for sin; r^2/2, r^4/24, r^6/720 for cos) in double-double arithmetic, the rest (seven terms) in
+ * double.  Error below 2^-65 of the result: correctly rounded but for about one argument in two thousand (fdlibm's k_sin / k_cos, which
+ * rounds 1-2 carried, differ from the correctly rounded value for ~3 % of the arguments). */
+static inline double eo_ksin(double rh, double rl, int unused_iy) {
+    (void)unused_iy;
+    uint32_t ix = eo_hi(rh) & 0x7fffffffu;
+    if (ix < 0x3e400000u) { if ((int)rh == 0) return rh; }      /* |r| < 2^-27 */
+    const double s1h = -0x1.5555555555555p-3, s1l = -0x1.5555555555555p-57;      /* -1/6 */
+    const double s2h = 0x1.1111111111111p-7, s2l = 0x1.1111111111111p-63;        /* 1/120 */
+    const double zh = rh * rh, zl = EO_FMA(rh, rh, -zh) + 2.0 * rh * rl;
+    const double t = -0x1.a01a01a01a01ap-13 + zh * (0x1.71de3a556c734p-19 + zh * (-0x1.ae64567f544e4p-26 + zh * (0x1.6124613a86d09p-33 +
+                     zh * (-0x1.ae7f3e733b81fp-41 + zh * (0x1.952c77030ad4ap-49 + zh * -0x1.2f49b46814157p-57)))));
+    double p = zh * t, e = EO_FMA(zh, t, -p);
+    const double l2h = s2h + p, l2l = ((s2h - l2h) + p) + (s2l + e);
+    p = zh * l2h; e = EO_FMA(zh, l2h, -p) + (zh * l2l + zl * l2h);
+    const double l1h = s1h + p, l1l = ((s1h - l1h) + p) + (s1l + e);
+    const double wh = zh * l1h, wl = EO_FMA(zh, l1h, -wh) + (zh * l1l + zl * l1h);
+    const double th = rh * wh, tl = EO_FMA(rh, wh, -th) + (rh * wl + rl * wh);
+    const double h = rh + th;
+    return h + (((rh - h) + th) + (rl + tl));
 }
 
-static inline double eo_kcos(double x, double y) {
-    uint32_t ix = eo_hi(x) & 0x7fffffffu;
-    if (ix < 0x3e400000u) { if ((int)x == 0) return 1.0; }
-    double z = x * x;
-    double r = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-               z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    if (ix < 0x3FD33333u) return 1.0 - (0.5 * z - (z * r - x * y));
-    double qx;
-    if (ix > 0x3fe90000u) qx = 0.28125; else qx = eo_from_words(ix - 0x00200000u, 0);
-    double hz = 0.5 * z - qx;
-    double a = 1.0 - qx;
-    return a - (hz - (z * r - x * y));
+static inline double eo_kcos(double rh, double rl) {
+    uint32_t ix = eo_hi(rh) & 0x7fffffffu;
+    if (ix < 0x3e400000u) { if ((int)rh == 0) return 1.0; }
+    const double c2h = 0x1.5555555555555p-5, c2l = 0x1.5555555555555p-59;        /* 1/24 */
+    const double c3h = -0x1.6c16c16c16c17p-10, c3l = 0x1.f49f49f49f49fp-65;      /* -1/720 */
+    const double zh = rh * rh, zl = EO_FMA(rh, rh, -zh) + 2.0 * rh * rl;
+    const double t = 0x1.a01a01a01a01ap-16 + zh * (-0x1.27e4fb7789f5cp-22 + zh * (0x1.1eed8eff8d898p-29 + zh * (-0x1.93974a8c07c9dp-37 +
+                     zh * (0x1.ae7f3e733b81fp-45 + zh * (-0x1.6827863b97d97p-53 + zh * 0x1.e542ba4020225p-62)))));
+    double p = zh * t, e = EO_FMA(zh, t, -p);
+    const double l3h = c3h + p, l3l = ((c3h - l3h) + p) + (c3l + e);
+    p = zh * l3h; e = EO_FMA(zh, l3h, -p) + (zh * l3l + zl * l3h);
+    const double l2h = c2h + p, l2l = ((c2h - l2h) + p) + (c2l + e);
+    p = zh * l2h; e = EO_FMA(zh, l2h, -p) + (zh * l2l + zl * l2h);
+    const double l1h = -0.5 + p, l1l = ((-0.5 - l1h) + p) + e;
+    const double wh = zh * l1h, wl = EO_FMA(zh, l1h, -wh) + (zh * l1l + zl * l1h);
+    const double h = 1.0 + wh;
+    return h + (((1.0 - h) + wh) + wl);
 }
 
 /* argument reduction: x = n*(pi/2) + y0 + y1, |y0+y1| <= pi/4.  Cody-Waite 3-stage path

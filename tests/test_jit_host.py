@@ -39,8 +39,13 @@ def test_linear_space_expressions_become_arithmetic():
 
 
 def test_hiprtc_compile_and_cache(tmp_path):
+    import json
     from euclider_amd import Parser
-    env = Parser().parse_file(os.path.join(ROOT, "scenes", "3d_fresnel.json"))
+    # a scene of its own (the shipped scenes' kernels may already sit in euclider_amd/jit_cache, which is consulted first)
+    text = open(os.path.join(ROOT, "scenes", "3d_fresnel.json")).read().replace("1.458", "1.4625")
+    assert text != open(os.path.join(ROOT, "scenes", "3d_fresnel.json")).read()
+    json.loads(text)
+    env = Parser(texture_dirs=[ROOT]).parse(text)
     cache = str(tmp_path / "cache")
     first = env.jit_precompile(cache)
     assert not first["from_cache"] and first["compile_ms"] > 0
@@ -49,7 +54,7 @@ def test_hiprtc_compile_and_cache(tmp_path):
     with open(os.path.join(cache, files[0]), "rb") as f:
         assert f.read(4) == b"\x7fELF"
     env.close()
-    env = Parser().parse_file(os.path.join(ROOT, "scenes", "3d_fresnel.json"))
+    env = Parser(texture_dirs=[ROOT]).parse(text)
     second = env.jit_precompile(cache)
     assert second["from_cache"] and second["key"] == first["key"]
     env.close()

@@ -1,6 +1,6 @@
-"""Elementary functions: the oracle's eo_math.h against glibc (<= 1 ulp), and the product's eu_math.h
-against the oracle's, bit for bit, both compiled for the host (the device side is checked in
-tests/test_gpu_parity.py::test_device_math_matches_oracle)."""
+"""Elementary functions: the oracle's eo_math.h against glibc (<= 1 ulp) and, for acos / asin / sin / cos, against the correctly rounded
+value (a 100-digit reference, tests/hp_reference.py); the product's eu_math.h against the oracle's, bit for bit, both compiled for
+the host (the device side is checked in tests/test_gpu_parity.py::test_device_math_matches_oracle)."""
 import ctypes as C
 import math
 import os
@@ -43,6 +43,24 @@ def test_oracle_math_within_one_ulp_of_libm(oracle_lib):
     # numpy's arctan2 is its own SIMD routine; compare with glibc's through math.atan2
     ref = np.array([math.atan2(p, q) for p, q in zip(y[:100000], z[:100000])])
     assert ulps(run(oracle_lib, 5, y[:100000], z[:100000]), ref).max() <= 1
+
+
+def test_acos_asin_sin_cos_are_correctly_rounded(oracle_lib):
+    """Round 3: these four return the correctly rounded double (by construction for all but ~2^-11 of the arguments).  glibc 2.35 -- what
+    Rust's f64 methods call -- differs from the correctly rounded value for 0.06-0.14 % of such arguments; rounds 1-2's fdlibm routines
+    for 3-8 %, which moved 2 % of 3d_room's bytes (tests/test_oracle_libm.py)."""
+    import random
+    import hp_reference as hp
+    rng = random.Random(17)
+    unit = [rng.uniform(-1, 1) for _ in range(1200)] + [math.copysign(1 - 10 ** rng.uniform(-12, -0.3), rng.uniform(-1, 1)) for _ in range(400)] + \
+           [10 ** rng.uniform(-30, -0.3) * rng.choice((-1, 1)) for _ in range(300)] + \
+           [0.5, -0.5, math.nextafter(0.5, 0), math.nextafter(0.5, 1), math.nextafter(1, 0), -math.nextafter(1, 0), 0.0, -0.0, 1.0, -1.0, 5e-324, 2.0 ** -27, 2.0 ** -28]
+    angle = [rng.uniform(-math.pi, math.pi) for _ in range(1200)] + [rng.uniform(-40, 40) for _ in range(400)] + [rng.uniform(-1e5, 1e5) for _ in range(200)] + \
+            [10 ** rng.uniform(-20, 0) * rng.choice((-1, 1)) for _ in range(200)] + [0.0, math.pi / 4, -math.pi / 4, math.nextafter(math.pi / 4, 1), math.pi / 2, math.pi, 2.0 ** -27, 1e-300]
+    for fn, ref, xs in ((0, hp.acos, unit), (1, hp.asin, unit), (2, hp.sin, angle), (3, hp.cos, angle)):
+        got = run(oracle_lib, fn, np.array(xs))
+        wrong = [(x, g) for x, g in zip(xs, got) if g != float(ref(x))]
+        assert len(wrong) <= 2, (fn, len(wrong), wrong[:3])          # expectation: 1 in 2000
 
 
 def test_oracle_math_special_values(oracle_lib):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stage = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "3d_room.json 1920x1080 depth 8"
 pmc_dir = sys.argv[4] if len(sys.argv) > 4 else "pmc"
-round_no = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+round_no = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 # one file per pass: gpurun MERGES its output into gpurun_out/, so an earlier refresh leaves its files (other run ids) beside the new ones
 latest = {}
@@ -31,7 +31,7 @@ for name, cs in vals.items():
     per_kernel[name] = {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
 for name in vals:
     n = per_kernel[name]["SQ_WAVES"]["launches"] if "SQ_WAVES" in per_kernel[name] else 0
-    if name.startswith("eu_wf_gen") or name.startswith("eu_ts_kernel"):
+    if "intersect0" in name:      # one generation-0 intersect launch per frame (single band stream, frames up to 4 Mpixel)
         frames = n
 for name in vals:
     n = max(v["launches"] for v in per_kernel[name].values())
@@ -49,14 +49,14 @@ for name in vals:
     derived[name] = d
 fetch = sum(launches[n] * per_kernel[n]["FETCH_SIZE"]["avg_per_launch"] * 1024 for n in vals if "FETCH_SIZE" in per_kernel[n])
 write = sum(launches[n] * per_kernel[n]["WRITE_SIZE"]["avg_per_launch"] * 1024 for n in vals if "WRITE_SIZE" in per_kernel[n])
-# Calibration on kernels of known traffic (this run): 4 B and 8 B per lane accesses read exactly (final kernel: 72.9 MB of
-# 8-B/4-B loads -> FETCH_SIZE 70.5 MB; gen kernel: 121.5 MB of stores -> WRITE_SIZE 122.1 MB); only the pack kernel's 16 B per
+# Calibration on kernels of known traffic (round 1: 4 B and 8 B per lane accesses read exactly -- a kernel reading 72.9 MB with
+# 8-B/4-B loads -> FETCH_SIZE 70.5 MB; one storing 121.5 MB -> WRITE_SIZE 122.1 MB); only the pack kernel's 16 B per
 # lane loads are reported at half (8.29 MB -> 4.16 MB), as MI355X_MICROARCH.md says for wide loads: its FETCH_SIZE is doubled.
 wide = [n for n in vals if n.startswith("eu_pack_rgb") and "FETCH_SIZE" in per_kernel[n]]
 fetch_corrected = fetch + sum(launches[n] * per_kernel[n]["FETCH_SIZE"]["avg_per_launch"] * 1024 for n in wide)
 valu = sum(launches[n] * derived[n].get("SQ_INSTS_VALU_per_launch", 0.0) for n in vals)
 lanes = sum(launches[n] * derived[n].get("SQ_INSTS_VALU_per_launch", 0.0) * derived[n].get("VALU_lane_utilisation_pct", 0.0) / 100 for n in vals)
-out = {"round": round_no, "stage": stage + "; counters collected with EU_WF_STREAMS=1 so that per-dispatch counters do not mix between concurrent kernels",
+out = {"round": round_no, "stage": stage + "; counters collected with one band stream (bench.py --streams 1) so that per-dispatch counters do not mix between concurrent kernels",
        "workload": workload, "launches_per_frame_single_stream": launches, "derived": derived, "per_kernel": per_kernel,
        "frame_hbm_bytes": {"FETCH_SIZE_sum": fetch, "WRITE_SIZE_sum": write, "hbm_bytes_per_frame_raw": fetch + write,
                            "hbm_bytes_per_frame_fetch_doubled": 2 * fetch + write, "hbm_bytes_per_frame_calibrated": fetch_corrected + write,
@@ -67,9 +67,9 @@ json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc.json"), "w"), ind
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
 t[workload] = {"hbm_bytes_per_launch": fetch_corrected + write, "fetch_bytes": fetch_corrected, "write_bytes": write,
-               "definition": "one 'launch' = the frame pipeline of one eu_render_device call (gen + 8 intersect + 8 shade + 8 resolve + final + pack per band); "
+               "definition": "one 'launch' = the frame pipeline of one eu_render_device call (per generation one intersect + one shade launch, then one resolve launch per generation, + pack); "
                              "FETCH_SIZE+WRITE_SIZE summed over its kernels (profiles/%s_pmc.json), FETCH_SIZE of the pack kernel (16 B/lane loads) doubled; "
-                             "calibrated on the final, gen and pack kernels, whose traffic is known: 4-8 B/lane accesses read exactly" % tag,
+                             "4-8 B/lane accesses read exactly (calibrated in round 1 on kernels of known traffic)" % tag,
                "valu_wave_insts_per_launch": valu, "valu_lane_utilisation": lanes / valu if valu else None,
                "valu_definition": "SQ_INSTS_VALU (wave-level VALU instructions) summed over the frame pipeline's kernels, and their mean active-lane share (profiles/%s_pmc.json)" % tag}
 json.dump(t, open(tp, "w"), indent=1)
