@@ -184,11 +184,11 @@ def valu_figure(workload_key, kernel_ms):
 
 def flops_figure(workload_key, rays, kernel_ms):
     """Compute roofline: f64 operations of the reference ALGORITHM per ray, counted by the oracle's instrumented
-    build (profiles/r02_oracle_flops.json; add/sub/mul, div, sqrt and transcendental calls count 1 each), times this frame's
+    build (profiles/r03_oracle_flops.json; add/sub/mul, div, sqrt and transcendental calls count 1 each), times this frame's
     rays, over the live kernel time, against the f64 vector peak.  The kernels execute several instructions per division,
     square root and transcendental call, so their own f64 instruction rate is higher than this figure (see `valu`)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_oracle_flops.json")))["workloads"].get(workload_key)
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_oracle_flops.json")))["workloads"].get(workload_key)
     except Exception:
         rec = None
     if not rec:

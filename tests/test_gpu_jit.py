@@ -1,0 +1,86 @@
+"""Scene-specialised kernels on the GPU: what eu_renderer_jit_info reports, the cache, the fall-back when the compilation fails, and
+parity of the specialised kernels with the interpreter kernels on inputs the parametrised suite does not reach."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.interpreter_only]      # (chooses its kernel paths itself)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
+
+
+def test_jit_info_and_cache(tmp_path):
+    from euclider_amd import Parser
+    text = open(os.path.join(SCENES, "3d_fresnel.json")).read().replace("1.458", "1.4375")      # a scene no cache knows yet
+    cache = str(tmp_path / "cache")
+    a = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="sync", cache_dir=cache)
+    img_a = a.render((96, 96))
+    info = a.jit_info()
+    assert info["requested"] and info["active"] and not info["from_cache"] and info["compile_ms"] > 0
+    assert os.listdir(cache) == [info["key"] + ".hsaco"]
+    a.close()
+    b = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="sync", cache_dir=cache)
+    img_b = b.render((96, 96))
+    assert b.jit_info()["from_cache"] and b.jit_info()["active"]
+    b.close()
+    c = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="off")
+    img_c = c.render((96, 96))
+    assert not c.jit_info()["requested"] and not c.jit_info()["active"]
+    c.close()
+    assert np.array_equal(img_a.data, img_c.data) and np.array_equal(img_b.data, img_c.data) and img_a.stats == img_c.stats
+
+
+def test_failed_compilation_falls_back_to_the_interpreter(tmp_path):
+    from euclider_amd import Parser
+    path = os.path.join(SCENES, "3d_room.json")
+    good = Parser().parse_file(path).configure(specialize="off")
+    good.camera.max_depth = 5
+    ref = good.render((160, 90))
+    good.close()
+    bad = Parser().parse_file(path).configure(specialize="sync", cache_dir=str(tmp_path), jit_flags="-DEU_DEV=this_does_not_compile")
+    bad.camera.max_depth = 5
+    img = bad.render((160, 90))
+    info = bad.jit_info()
+    bad.close()
+    assert info["requested"] and not info["active"]
+    assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
+
+
+def test_opts_struct_of_an_older_caller():
+    """struct_size smaller than the library's eu_renderer_opts: the fields beyond it keep their defaults."""
+    from euclider_amd import Parser, _capi
+    env = Parser().parse_file(os.path.join(SCENES, "3d_fresnel.json"))
+    L = _capi.lib()
+    opts = _capi.RendererOpts()
+    opts.struct_size = 16                      # struct_size, kernel, specialize, streams only
+    opts.kernel = _capi.EU_KERNEL_STACK
+    opts.ray_factor = -1.0                     # would be refused if it were read
+    out, err = C.c_void_p(), C.create_string_buffer(256)
+    assert L.eu_renderer_create_opts(env._scene, 0, C.byref(opts), C.byref(out), err, len(err)) == _capi.EU_OK, err.value
+    L.eu_renderer_destroy(out)
+    opts.struct_size = C.sizeof(_capi.RendererOpts)
+    assert L.eu_renderer_create_opts(env._scene, 0, C.byref(opts), C.byref(out), err, len(err)) == _capi.EU_ERR_INVALID_ARGUMENT
+    env.close()
+
+
+@pytest.mark.parametrize("scene,depth", [("3d_room.json", 8), ("3d_hallways.json", 12), ("4d_frame.json", 8)])
+def test_sequence_and_trace_screen_point_on_specialised_kernels(scene, depth):
+    """The frame sequence (renderer clones per slot) and the single-pixel path with specialised kernels against the interpreter's."""
+    from euclider_amd import FrameSequence, Parser
+    path = os.path.join(SCENES, scene)
+    a = Parser().parse_file(path).configure(specialize="off")
+    a.camera.max_depth = depth
+    ref = a.render((192, 108))
+    pts = [a.trace_screen_point(0.0, depth, x, y, 192, 108) for (x, y) in ((0, 0), (95, 54), (191, 107))]
+    a.close()
+    b = Parser().parse_file(path).configure(specialize="sync")
+    b.camera.max_depth = depth
+    with FrameSequence(b, (192, 108), slots=3) as seq:
+        for _ in range(3):
+            seq.submit((192, 108))
+        frames = [seq.next() for _ in range(3)]
+    assert all(np.array_equal(f.data, ref.data) and f.stats == ref.stats for f in frames)
+    assert [b.trace_screen_point(0.0, depth, x, y, 192, 108) for (x, y) in ((0, 0), (95, 54), (191, 107))] == pts
+    b.close()

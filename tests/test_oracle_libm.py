@@ -1,11 +1,12 @@
 """How far does the last bit of the elementary functions move the picture?
 
 The reference calls the platform libm (Rust's f64::acos/asin/sin/cos/tan/atan2); the oracle and the HIP kernels share their
-own fdlibm-style routines (oracle/eo_math.h, csrc/eu_math.h), which differ from glibc by at most 1 ulp -- in 3-18 % of
-the arguments.  `libeo_oracle_libm.so` is the same restatement with glibc's functions.  This test renders the BASELINE
-configurations with both and reports the differing RGB bytes and ray counts (numbers at full size: DESIGN.md section 2).
+own routines (oracle/eo_math.h, csrc/eu_math.h).  `libeo_oracle_libm.so` is the same restatement with glibc's functions.  This test
+renders the BASELINE configurations with both and reports the differing RGB bytes and ray counts (numbers at full size: DESIGN.md
+section 2).  Rounds 1-2 (fdlibm-style routines, 1 ulp from glibc for 3-18 % of the arguments): 2.08 % of 3d_room's bytes differed.
+Round 3 (acos / asin / sin / cos correctly rounded; glibc itself is for all but 0.06-0.14 % of the arguments): 0.02 %.
 
-What it pins: a 1-ulp difference never moves a byte by more than 1, and moves a bounded share of them; the mechanism is the
+What it pins: a 1-ulp difference never moves a byte by more than 1, and moves a small share of them; the mechanism is the
 `alpha == 255` test of get_intersection_color (surface.rs:73): an opaque blend's alpha is (sa + 1) - sa, i.e. 1 or 1 - 2^-53
 depending on sa's last bit, 255 or 254 after to_pixel's truncation.
 """
@@ -31,7 +32,7 @@ def test_libm_last_bit_sensitivity(scene, w, h, depth, capsys):
         print("\n  %-18s %dx%d d%-2d: %6d of %d bytes differ (%.2f %%), max |diff| %d, rays %d vs %d" % (
             scene, w, h, depth, int((d != 0).sum()), d.size, 100.0 * (d != 0).mean(), int(d.max()), sa["rays"], sb["rays"]))
     assert int(d.max()) <= 1
-    assert (d != 0).mean() < 0.08
+    assert (d != 0).mean() < 0.002          # (round 2: < 0.08)
     assert abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
 
 

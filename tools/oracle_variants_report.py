@@ -1,6 +1,6 @@
 """Full-size numbers of the oracle's measurement builds for the BASELINE configurations (CPU only):
-  - f64 operations of the reference algorithm per ray (libeo_oracle_flops.so)      -> profiles/r02_oracle_flops.json
-  - RGB bytes / rays that change when glibc's libm replaces eo_math.h (libeo_oracle_libm.so) -> profiles/r02_oracle_libm.json
+  - f64 operations of the reference algorithm per ray (libeo_oracle_flops.so)      -> profiles/r03_oracle_flops.json
+  - RGB bytes / rays that change when glibc's libm replaces eo_math.h (libeo_oracle_libm.so) -> profiles/r03_oracle_libm.json
 Usage: python tools/oracle_variants_report.py"""
 import json
 import os
@@ -34,6 +34,6 @@ for scene, w, h, depth in CONFIGS:
         libm[key]["bytes_differing"], 100 * libm[key]["share"], sb["rays"] - rays), flush=True)
 note = ("counting rule: add/sub/mul = 1 each, div (and fmod) = 1, sqrt = 1, calls of acos/asin/sin/cos/tan/atan/atan2 = 1 each; negation, abs, "
         "floor, compares, selects and integer work are not counted; counted where the oracle (the reference's lazy algorithm) performs them")
-json.dump({"note": note, "workloads": flops}, open(os.path.join(ROOT, "profiles", "r02_oracle_flops.json"), "w"), indent=1)
+json.dump({"note": note, "workloads": flops}, open(os.path.join(ROOT, "profiles", "r03_oracle_flops.json"), "w"), indent=1)
 json.dump({"note": "RGB8 frame and ray count of the oracle built with glibc's libm (what Rust's f64 methods call on Linux) versus the shipped oracle (eo_math.h, <= 1 ulp from glibc)",
-           "workloads": libm}, open(os.path.join(ROOT, "profiles", "r02_oracle_libm.json"), "w"), indent=1)
+           "workloads": libm}, open(os.path.join(ROOT, "profiles", "r03_oracle_libm.json"), "w"), indent=1)
