@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0, help="band pipelines in flight per frame (0 = the library's default)")
     ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
     ap.add_argument("--renderer-flags", type=int, default=0, help="eu_renderer_opts.flags")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 5: measured "
+                         "1 / 3 / 4 / 5 / 6 in flight = 6.1 / 6.6 / 7.3 / 7.6 / 7.1 Gray/s on config 2; 1 = one frame at a time on two band streams)")
     ap.add_argument("--abi-child", type=int, default=0,
                     help="internal: ONE process drives this many GPUs through the C ABI (eu_render_multi) on the 8K frame and prints a JSON object")
     return ap.parse_args()
@@ -272,45 +275,54 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def other_configs(torch, dev, stream, Parser, args):
-    """BASELINE.json configs 3 and 4, the extra 4-D scene and the 8K frame on one GPU: a few steps each, so that the driver's
-    record carries them too.  Same timing rule as the headline (device-resident, synchronised on both sides)."""
+def other_configs(torch, dev, Parser, args, in_flight):
+    """BASELINE.json configs 3 and 4, the extra 4-D scene, the 8K frame on one GPU, the reference's own depth and the f32 build: a few
+    steps each, so that the driver's record carries them too.  Same timing rule as the headline (device-resident, synchronised on both
+    sides, the same number of frames in flight; two for the 8K frame, whose bands are 4 Mpixel each)."""
     out = []
-    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 12, False), ("4d_frame.json", 1920, 1080, 8, 12, False),
-                                          ("4d_cylinders.json", 1920, 1080, 8, 8, False), ("3d_room.json", 7680, 4320, 8, 3, False),
-                                          ("3d_room.json", 1920, 1080, 10, 12, False), ("3d_room.json", 1920, 1080, 8, 12, True)):
-        env = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
-        env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
-        env.camera.max_depth = depth
+    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 20, False), ("4d_frame.json", 1920, 1080, 8, 20, False),
+                                          ("4d_cylinders.json", 1920, 1080, 8, 15, False), ("3d_room.json", 7680, 4320, 8, 4, False),
+                                          ("3d_room.json", 1920, 1080, 10, 20, False), ("3d_room.json", 1920, 1080, 8, 20, True)):
+        R = min(in_flight, 2) if W * H > (4 << 20) else in_flight
+        envs = []
+        for _ in range(R):
+            e = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
+            e.configure(specialize=args.specialize, streams=args.streams or (1 if R > 1 else 0), jit_flags=args.jit_flags, flags=args.renderer_flags)
+            e.camera.max_depth = depth
+            envs.append(e)
+        env = envs[0]
         frame = env.frame(W, H, time=0.0, rows=(0, H))
-        rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
-        rgb = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(R)]
+        rgba = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(R)]
+        rgb = [torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) for _ in range(R)]
 
-        def step():
-            env.render_device(frame, rgba.data_ptr(), None, stream, device=dev.index)
-            env.pack_rgb_device(rgba.data_ptr(), rgb.data_ptr(), H * W, stream, device=dev.index)
-        step()
-        step()
+        def step(k):
+            j = k % R
+            envs[j].render_device(frame, rgba[j].data_ptr(), None, streams[j].cuda_stream, device=dev.index)
+            envs[j].pack_rgb_device(rgba[j].data_ptr(), rgb[j].data_ptr(), H * W, streams[j].cuda_stream, device=dev.index)
+        for k in range(2 * R):
+            step(k)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for k in range(steps):
+            step(k)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / steps
         st = env.stats(device=dev.index)
-        kms = env.kernel_ms_history(steps, device=dev.index)
-        kernel_ms = sum(kms) / max(1, len(kms))
+        agree = all(torch.equal(rgb[0][:H * W * 3], x[:H * W * 3]) for x in rgb[1:])
+        kernel_ms = dt * 1e3      # a frame's share of the device (frames overlap; see the headline's roofline)
         alg = 4.0 * W * H + 16.0 * st["bg_samples"] + env.info.flat_bytes
         ach = alg / (kernel_ms * 1e-3) / 1e9
         out.append({"workload": "%s %dx%d depth %d%s" % (scene, W, H, depth, ", low_precision (F = f32, its own rays and pixels)" if lp else ""),
                     "dtype": "f32" if lp else "f64", "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
-                    "ms_per_step": dt * 1e3, "steps": steps, "rays_per_frame": int(st["rays"]),
+                    "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": R, "slots_agree": agree, "rays_per_frame": int(st["rays"]),
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
                                  "flops": None if lp else flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)},
                     "specialized": env.jit_info(device=dev.index)["active"]})
-        env.close()
+        for e in envs:
+            e.close()
         del rgba, rgb
     return out
 
@@ -351,9 +363,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
-    env = Parser(low_precision=args.low_precision).parse_file(scene_path)
-    env.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
-    env.camera.max_depth = args.max_depth
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 5
+    band_streams = args.streams or (1 if in_flight > 1 else 0)      # frames in flight fill each other's kernel tails; a lone frame is cut into two bands for that
+
+    def make_env():
+        e = Parser(low_precision=args.low_precision).parse_file(scene_path)
+        e.configure(specialize=args.specialize, streams=band_streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
+        e.camera.max_depth = args.max_depth
+        return e
+    env = make_env()
+    envs = [env]
     jit = env.jit_info(device=local_rank)      # (creates the renderer: a specialised one compiles or fetches its kernels here, before any timing)
     if args.specialize == "sync" and not jit["active"]:
         raise SystemExit("bench.py: the specialised kernels did not build; run with --specialize off to time the interpreter kernels")
@@ -363,10 +382,14 @@ def main():
         animate(args, env, scene_path)
         env.close()
         return
-    def timed_run(W, H, steps, warmup):
+    def timed_run(W, H, steps, warmup, n_slots):
         """K steps of the partitioned frame (this rank's strips traced, packed, gathered on rank 0, rows restored), timed
-        between barriers + device synchronisation; returns max-over-ranks wall time and summed counters."""
+        between barriers + device synchronisation; returns max-over-ranks wall time and summed counters.  Step k uses slot k % n_slots:
+        a renderer, a stream and buffers of its own, so that up to n_slots frames are in flight (the production frame loop,
+        eu_sequence_*, does the same)."""
         strips = (rank, world) if world > 1 else None
+        while len(envs) < n_slots:
+            envs.append(make_env())
         frame = env.frame(W, H, time=0.0, rows=(0, H), strips=strips)
         local_rows = env.local_rows(frame)
         if world > 1:      # equal counts for the gather: pad to the largest rank
@@ -375,38 +398,45 @@ def main():
             max_rows = int(t.item())
         else:
             max_rows = local_rows
-        rgba = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        gathered = allbuf = perm = full = rgb_local = None
-        rgb_out = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None
-        if world > 1:
-            # every rank packs its own strips to RGB8 before the gather (3 bytes per pixel travel, not 4; the root only reorders rows)
-            rgb_local = torch.empty((max_rows, W * 3), dtype=torch.uint8, device=dev)
-            if rank == 0:
-                allbuf = torch.empty((world * max_rows, W * 3), dtype=torch.uint8, device=dev)   # the gather lands in place: no concatenation
-                gathered = [allbuf[k * max_rows:(k + 1) * max_rows] for k in range(world)]
-                from euclider_amd.partition import gather_permutation
-                perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
-                full = rgb_out[:H * W * 3].view(H, W * 3)
-
-        def step():
-            env.render_device(frame, rgba.data_ptr(), None, stream, device=local_rank)
+        perm = None
+        if world > 1 and rank == 0:
+            from euclider_amd.partition import gather_permutation
+            perm = torch.tensor(gather_permutation(H, world, max_rows), dtype=torch.int64, device=dev)
+        slots = []
+        for j in range(n_slots):
+            sl = {"env": envs[j], "stream": torch.cuda.Stream(dev) if n_slots > 1 else torch.cuda.current_stream(dev),
+                  "rgba": torch.zeros((max_rows, W), dtype=torch.int32, device=dev),
+                  "rgb_out": torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev) if rank == 0 else None}
             if world > 1:
-                env.pack_rgb_device(rgba.data_ptr(), rgb_local.data_ptr(), max_rows * W, stream, device=local_rank)
-                if smoke_gloo:                                          # one-GPU rehearsal only (see above)
-                    torch.cuda.synchronize(dev)
-                    host = rgb_local.cpu()
-                    hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                    dist.gather(host, hg, dst=0)
-                    if rank == 0:
-                        for k in range(world):
-                            gathered[k].copy_(hg[k])
-                else:
-                    dist.gather(rgb_local, gathered, dst=0)             # the single RCCL gather
+                # every rank packs its own strips to RGB8 before the gather (3 bytes per pixel travel, not 4; the root only reorders rows)
+                sl["rgb_local"] = torch.empty((max_rows, W * 3), dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    torch.index_select(allbuf, 0, perm, out=full)       # rows back in frame order = the RawImage2d
-            else:
-                env.pack_rgb_device(rgba.data_ptr(), rgb_out.data_ptr(), H * W, stream, device=local_rank)
+                    sl["allbuf"] = torch.empty((world * max_rows, W * 3), dtype=torch.uint8, device=dev)   # the gather lands in place: no concatenation
+                    sl["gathered"] = [sl["allbuf"][k * max_rows:(k + 1) * max_rows] for k in range(world)]
+                    sl["full"] = sl["rgb_out"][:H * W * 3].view(H, W * 3)
+            slots.append(sl)
+
+        def step(k):
+            sl = slots[k % n_slots]
+            e, raw = sl["env"], sl["stream"].cuda_stream
+            with torch.cuda.stream(sl["stream"]):
+                e.render_device(frame, sl["rgba"].data_ptr(), None, raw, device=local_rank)
+                if world > 1:
+                    e.pack_rgb_device(sl["rgba"].data_ptr(), sl["rgb_local"].data_ptr(), max_rows * W, raw, device=local_rank)
+                    if smoke_gloo:                                          # one-GPU rehearsal only (see above)
+                        torch.cuda.synchronize(dev)
+                        host = sl["rgb_local"].cpu()
+                        hg = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                        dist.gather(host, hg, dst=0)
+                        if rank == 0:
+                            for q in range(world):
+                                sl["gathered"][q].copy_(hg[q])
+                    else:
+                        dist.gather(sl["rgb_local"], sl.get("gathered"), dst=0)             # the single RCCL gather
+                    if rank == 0:
+                        torch.index_select(sl["allbuf"], 0, perm, out=sl["full"])       # rows back in frame order = the RawImage2d
+                else:
+                    e.pack_rgb_device(sl["rgba"].data_ptr(), sl["rgb_out"].data_ptr(), H * W, raw, device=local_rank)
 
         def sync():
             torch.cuda.synchronize(dev)
@@ -414,16 +444,25 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
-        for _ in range(warmup):
-            step()
+        for k in range(max(warmup, n_slots)):      # (every slot's renderer sizes its buffers on its first frame)
+            step(k)
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for k in range(steps):
+            step(k)
         sync()
         elapsed = time.perf_counter() - t0
         st = env.stats(device=local_rank)
-        kms = env.kernel_ms_history(min(steps, 64), device=local_rank)
+        # one frame alone (slot 0, nothing else in flight): the latency next to the pipelined throughput
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(0)
+            torch.cuda.synchronize(dev)
+        alone_ms = (time.perf_counter() - t1) / 3 * 1e3
+        kms = env.kernel_ms_history(3, device=local_rank)
+        same = True
+        if rank == 0 and n_slots > 1:      # every slot rendered the same frame: their images must be identical
+            same = all(torch.equal(slots[0]["rgb_out"][:H * W * 3], sl["rgb_out"][:H * W * 3]) for sl in slots[1:])
         rdev = torch.device("cpu") if smoke_gloo else dev
         tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=rdev)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -431,18 +470,18 @@ def main():
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return {"W": W, "H": H, "elapsed": tmax.item(), "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
-                "local_rows": local_rows, "rgb_out": rgb_out, "steps": steps}
+                "local_rows": local_rows, "rgb_out": slots[0]["rgb_out"], "steps": steps, "alone_ms": alone_ms, "slots_agree": same}
 
     parity_failed = False
     W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
-    run = timed_run(W, H, args.steps, args.warmup)
+    run = timed_run(W, H, args.steps, args.warmup, in_flight)
     elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
     tot = [run["rays"], 0.0, run["panic"]]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     cfg5 = cfg5_abi = None
     if world > 1 and not args.fixed_frame:      # BASELINE config 5 next to the weak-scaling value: the 8K frame over the same ranks (strong scaling)
-        r5 = timed_run(7680, 4320, 3, 1)
+        r5 = timed_run(7680, 4320, 4, 1, min(in_flight, 2))
         cfg5 = {"workload": "%s 7680x4320 depth %d, %d ranks" % (args.scene, args.max_depth, world), "scaling": "strong",
                 "value": r5["rays"] * r5["steps"] / r5["elapsed"] / 1e6, "unit": "Mray/s", "ms_per_step": r5["elapsed"] / r5["steps"] * 1e3,
                 "steps": r5["steps"], "rays_per_frame": int(r5["rays"])}
@@ -463,7 +502,10 @@ def main():
         np.save(os.environ["EU_BENCH_DUMP"], rgb_out[:H * W * 3].cpu().numpy().reshape(H, W, 3))
     if rank == 0:
         value = rays_per_step * args.steps / elapsed / 1e6
-        kernel_ms = sum(kms) / max(1, len(kms))
+        # device time per frame: with frames in flight the pipelines overlap, so a frame's share of the device is the timed region / steps (HIP
+        # events bracket it: torch.cuda.synchronize on both sides); `frame_alone_kernel_ms` is the HIP-event span of one frame's pipeline on its own
+        alone_kernel_ms = sum(kms) / max(1, len(kms))
+        kernel_ms = elapsed / args.steps * 1e3 if in_flight > 1 else alone_kernel_ms
         # algorithmic bytes of ONE launch of the trace kernel on this rank (DESIGN.md "Roofline"):
         # 4 B RGBA8 store per pixel + 16 B (4 RGBA8 texels) per background sample + the flat scene once
         alg_bytes = 4.0 * local_rows * W + 16.0 * st["bg_samples"] + env.info.flat_bytes
@@ -477,6 +519,10 @@ def main():
             "config": {"workload": workload + (" low_precision (F = f32: a separate mode, not the headline)" if args.low_precision else ""), "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
+                       "frames_in_flight": in_flight, "band_streams_per_frame": band_streams or "library default (2 for this scene)",
+                       "one_frame_alone": {"ms": run["alone_ms"], "Mray/s": rays_per_step / run["alone_ms"] / 1e3, "kernel_ms": alone_kernel_ms,
+                                           "note": "the same renderer with nothing else in flight (latency of one frame)"},
+                       "slots_agree": run["slots_agree"],
                        "kernels": ("specialised for the scene at renderer creation (hiprtc%s, %.0f ms)" % (", code object from the cache" if jit["from_cache"] else "", jit["compile_ms"])) if jit["active"] else "ahead-of-time, interpreting the flat scene",
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
                        "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
@@ -503,11 +549,12 @@ def main():
                              "checked_against": "oracle/ (CPU restatement), same scene, camera, frame"}
         if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json" and not args.low_precision:
             del rgb_out
-            out["other_configs"] = other_configs(torch, dev, stream, Parser, args)
+            out["other_configs"] = other_configs(torch, dev, Parser, args, in_flight)
         print(json.dumps(out), flush=True)
-        if out.get("parity", {}).get("mismatch"):
+        if out.get("parity", {}).get("mismatch") or not run["slots_agree"]:
             parity_failed = True
-    env.close()
+    for e in envs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
     if parity_failed:
