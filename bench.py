@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--animate", action="store_true",
                     help="N=1 only, not the headline: fly-through (Camera::update through trace_path each frame) with the frame "
                          "sequence driver, images read back to pinned host memory -- the PCIe-inclusive rate")
-    ap.add_argument("--slots", type=int, default=2, help="--animate: frames in flight")
+    ap.add_argument("--slots", type=int, default=4, help="--animate: frames in flight")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = whole frame")
     ap.add_argument("--low-precision", action="store_true",
                     help="F = f32: the reference's `low_precision` cargo feature (libeuclider_amd_f32.so against libeo_oracle_f32.so). "

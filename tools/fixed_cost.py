@@ -1,4 +1,4 @@
-"""Diagnostic: frame pipeline time for tiny frames = the fixed cost of its ~27 launches."""
+"""Diagnostic: frame pipeline time for tiny frames = the fixed cost of its launches.  Usage: python tools/fixed_cost.py [sync|off] [scene depth]"""
 import os
 import sys
 
@@ -6,8 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from euclider_amd import Parser  # noqa: E402
 
-env = Parser().parse_file(os.path.join(ROOT, "scenes", "3d_room.json"))
-env.camera.max_depth = 8
+spec = sys.argv[1] if len(sys.argv) > 1 else "sync"
+scene = sys.argv[2] if len(sys.argv) > 2 else "3d_room.json"
+env = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize=spec)
+env.camera.max_depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+print(scene, "depth", env.camera.max_depth, "specialize", spec)
 for w, h in ((64, 64), (256, 256), (640, 360), (960, 540), (1920, 1080)):
     for _ in range(5):
         img = env.render((w, h))
