@@ -27,11 +27,20 @@ typedef double real;
 #define R(x) ((real)(x))
 
 /* the elementary functions are evaluated in f64 (eu_math.h) and rounded to F at once, so that no expression continues in double
- * behind a call (in the default build the casts are no-ops); eu_*_f64 are the untouched entry points */
+ * behind a call (in the default build the casts are no-ops); eu_*_f64 are the untouched entry points.  F = f32: acos / asin / sin / cos
+ * take the 1-ulp f64 routines (eu_*32): after the rounding to f32 they give the correctly rounded f32 value but for one argument in 2^28,
+ * and the double-double routines of the f64 build would cost a tenth of the frame rate for nothing. */
+#if EU_REAL_BITS == 32
+#define eu_acos(x) ((real)eu_acos32(x))
+#define eu_asin(x) ((real)eu_asin32(x))
+#define eu_sin(x) ((real)eu_sin32(x))
+#define eu_cos(x) ((real)eu_cos32(x))
+#else
 #define eu_acos(x) ((real)eu_acos(x))
 #define eu_asin(x) ((real)eu_asin(x))
 #define eu_sin(x) ((real)eu_sin(x))
 #define eu_cos(x) ((real)eu_cos(x))
+#endif
 #define eu_tan(x) ((real)eu_tan(x))
 #define eu_atan(x) ((real)eu_atan(x))
 #define eu_atan2(y, x) ((real)eu_atan2(y, x))

@@ -373,4 +373,134 @@ static inline double eo_atan2(double y, double x) {
     }
 }
 
+/* ---- acos / asin / sin / cos for the F = f32 build: fdlibm 5.3's e_acos, e_asin, k_sin, k_cos (the routines rounds 1-2 used for f64 as
+ * well): within 1 ulp of the f64 value, which is then rounded to f32 -- the correctly rounded f32 result unless the true value lies
+ * within 2^-53 of an f32 rounding boundary (one argument in 2^28).  The double-double routines above would buy nothing there and cost
+ * a tenth of the f32 frame rate. ---- */
+/* rational approximation shared by acos and asin: R(z) = p(z)/q(z) */
+static inline double eo_asin_p32(double z) {
+    return z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
+           z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+}
+static inline double eo_asin_q32(double z) {
+    return 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 +
+           z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+}
+
+static inline double eo_acos32(double x) {
+    uint32_t hx = eo_hi(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3ff00000u) {                     /* |x| >= 1 */
+        if (((ix - 0x3ff00000u) | eo_lo(x)) == 0) {
+            if ((int32_t)hx > 0) return 0.0;
+            return EO_PI + 2.0 * EO_PIO2_LO;
+        }
+        return (x - x) / (x - x);                /* NaN */
+    }
+    if (ix < 0x3fe00000u) {                      /* |x| < 0.5 */
+        if (ix <= 0x3c600000u) return EO_PIO2_HI + EO_PIO2_LO;
+        double z = x * x;
+        double r = eo_asin_p32(z) / eo_asin_q32(z);
+        return EO_PIO2_HI - (x - (EO_PIO2_LO - x * r));
+    } else if ((int32_t)hx < 0) {                /* x < -0.5 */
+        double z = (1.0 + x) * 0.5;
+        double p = eo_asin_p32(z), q = eo_asin_q32(z);
+        double s = sqrt(z);
+        double r = p / q;
+        double w = r * s - EO_PIO2_LO;
+        return EO_PI - 2.0 * (s + w);
+    } else {                                     /* x > 0.5 */
+        double z = (1.0 - x) * 0.5;
+        double s = sqrt(z);
+        double df = eo_clear_lo(s);
+        double c = (z - df * df) / (s + df);
+        double p = eo_asin_p32(z), q = eo_asin_q32(z);
+        double r = p / q;
+        double w = r * s + c;
+        return 2.0 * (df + w);
+    }
+}
+
+static inline double eo_asin32(double x) {
+    uint32_t hx = eo_hi(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3ff00000u) {
+        if (((ix - 0x3ff00000u) | eo_lo(x)) == 0) return x * EO_PIO2_HI + x * EO_PIO2_LO;
+        return (x - x) / (x - x);
+    } else if (ix < 0x3fe00000u) {
+        if (ix < 0x3e400000u) return x;          /* |x| < 2^-27 */
+        double t = x * x;
+        double w = eo_asin_p32(t) / eo_asin_q32(t);
+        return x + x * w;
+    }
+    double w = 1.0 - fabs(x);
+    double t = w * 0.5;
+    double p = eo_asin_p32(t), q = eo_asin_q32(t);
+    double s = sqrt(t);
+    if (ix >= 0x3FEF3333u) {                     /* |x| > 0.975 */
+        w = p / q;
+        t = EO_PIO2_HI - (2.0 * (s + s * w) - EO_PIO2_LO);
+    } else {
+        w = eo_clear_lo(s);
+        double c = (t - w * w) / (s + w);
+        double r = p / q;
+        p = 2.0 * s * r - (EO_PIO2_LO - 2.0 * c);
+        q = EO_PIO4_HI - 2.0 * w;
+        t = EO_PIO4_HI - (p - q);
+    }
+    return ((int32_t)hx > 0) ? t : -t;
+}
+
+static inline double eo_ksin32(double x, double y, int iy) {
+    uint32_t ix = eo_hi(x) & 0x7fffffffu;
+    if (ix < 0x3e400000u) { if ((int)x == 0) return x; }
+    double z = x * x;
+    double v = z * x;
+    double r = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+               z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    if (iy == 0) return x + v * (-1.66666666666666324348e-01 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01);
+}
+
+static inline double eo_kcos32(double x, double y) {
+    uint32_t ix = eo_hi(x) & 0x7fffffffu;
+    if (ix < 0x3e400000u) { if ((int)x == 0) return 1.0; }
+    double z = x * x;
+    double r = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+               z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    if (ix < 0x3FD33333u) return 1.0 - (0.5 * z - (z * r - x * y));
+    double qx;
+    if (ix > 0x3fe90000u) qx = 0.28125; else qx = eo_from_words(ix - 0x00200000u, 0);
+    double hz = 0.5 * z - qx;
+    double a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+
+static inline double eo_sin32(double x) {
+    uint32_t ix = eo_hi(x) & 0x7fffffffu;
+    if (ix <= 0x3fe921fbu) return eo_ksin32(x, 0.0, 0);
+    if (ix >= 0x7ff00000u) return x - x;
+    double y0, y1;
+    int n = eo_rem_pio2(x, &y0, &y1);
+    switch (n & 3) {
+        case 0: return eo_ksin32(y0, y1, 1);
+        case 1: return eo_kcos32(y0, y1);
+        case 2: return -eo_ksin32(y0, y1, 1);
+        default: return -eo_kcos32(y0, y1);
+    }
+}
+
+static inline double eo_cos32(double x) {
+    uint32_t ix = eo_hi(x) & 0x7fffffffu;
+    if (ix <= 0x3fe921fbu) return eo_kcos32(x, 0.0);
+    if (ix >= 0x7ff00000u) return x - x;
+    double y0, y1;
+    int n = eo_rem_pio2(x, &y0, &y1);
+    switch (n & 3) {
+        case 0: return eo_kcos32(y0, y1);
+        case 1: return -eo_ksin32(y0, y1, 1);
+        case 2: return -eo_kcos32(y0, y1);
+        default: return eo_ksin32(y0, y1, 1);
+    }
+}
+
+
 #endif /* EO_MATH_H */

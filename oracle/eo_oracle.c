@@ -185,10 +185,17 @@ static inline eo_f64 eo_cnt_d_(eo_f64 v) { FLD(1); return v; }
 #define eo_cnt_d_(v) (v)
 #endif
 /* every elementary function of the path: evaluated in f64 (eo_math.h or libm), counted, rounded to F at once */
+#if defined(EO_LOW_PRECISION) && !defined(EO_USE_LIBM)      /* F = f32: the 1-ulp f64 routines, rounded to f32 (eo_math.h: correctly rounded f32 but for one argument in 2^28) */
+#define eo_acos(x) ((double)eo_cnt_t_(eo_acos32(x)))
+#define eo_asin(x) ((double)eo_cnt_t_(eo_asin32(x)))
+#define eo_sin(x) ((double)eo_cnt_t_(eo_sin32(x)))
+#define eo_cos(x) ((double)eo_cnt_t_(eo_cos32(x)))
+#else
 #define eo_acos(x) ((double)eo_cnt_t_(EO_FN(acos)(x)))
 #define eo_asin(x) ((double)eo_cnt_t_(EO_FN(asin)(x)))
 #define eo_sin(x) ((double)eo_cnt_t_(EO_FN(sin)(x)))
 #define eo_cos(x) ((double)eo_cnt_t_(EO_FN(cos)(x)))
+#endif
 #define eo_tan(x) ((double)eo_cnt_t_(EO_FN(tan)(x)))
 #define eo_atan(x) ((double)eo_cnt_t_(EO_FN(atan)(x)))
 #define eo_atan2(y, x) ((double)eo_cnt_t_(EO_FN(atan2)(y, x)))

@@ -39,7 +39,7 @@ def test_failed_compilation_falls_back_to_the_interpreter(tmp_path):
     good.camera.max_depth = 5
     ref = good.render((160, 90))
     good.close()
-    bad = Parser().parse_file(path).configure(specialize="sync", cache_dir=str(tmp_path), jit_flags="-DEU_DEV=this_does_not_compile")
+    bad = Parser().parse_file(path).configure(specialize="sync", cache_dir=str(tmp_path), jit_flags="-DEU_TRACE_WAVEFRONT_H=1")      # (the kernels' header skips itself: the compilation fails)
     bad.camera.max_depth = 5
     img = bad.render((160, 90))
     info = bad.jit_info()

@@ -85,8 +85,8 @@ extern "C" {
 int main() { srand(5); long bad = 0;
   for (int i = 0; i < 2000000; i++) {
     double x = (rand() / (double)RAND_MAX * 2 - 1) * (i %% 3 ? 1.0 : 50.0), y = (rand() / (double)RAND_MAX * 2 - 1) * 5;
-    double a[7] = {eu_acos(x), eu_asin(x), eu_sin(x), eu_cos(x), eu_tan(x), eu_atan2(x, y), eu_atan(x)};
-    double b[7] = {eo_acos(x), eo_asin(x), eo_sin(x), eo_cos(x), eo_tan(x), eo_atan2(x, y), eo_atan(x)};
+    double a[11] = {eu_acos(x), eu_asin(x), eu_sin(x), eu_cos(x), eu_tan(x), eu_atan2(x, y), eu_atan(x), eu_acos32(x), eu_asin32(x), eu_sin32(x), eu_cos32(x)};
+    double b[11] = {eo_acos(x), eo_asin(x), eo_sin(x), eo_cos(x), eo_tan(x), eo_atan2(x, y), eo_atan(x), eo_acos32(x), eo_asin32(x), eo_sin32(x), eo_cos32(x)};
     if (memcmp(a, b, sizeof a)) bad++; }
   printf("%%ld\n", bad); return bad != 0; }
 ''' % (ROOT, ROOT))
