@@ -4,7 +4,10 @@
 One "step" = one Environment::render pass: every pixel of the frame is traced by the HIP
 wavefront pipeline (intersect + shade per generation, resolve; scene, textures and the output frame resident in HBM; by default with
 kernels specialised for the scene, compiled when the renderer is created) and the
-RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.
+RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.  Steps are issued round-robin to `--frames-in-flight`
+renderers (default 5), each with a stream and buffers of its own, so that consecutive frames overlap on the device the way the frame
+loop of the C ABI (eu_sequence_*) overlaps them; the timed region still holds exactly K whole frames between two device
+synchronisations, and `config.one_frame_alone` carries the time of a single frame with nothing else in flight.
 
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
   N > 1 : the frame grows with N (weak scaling: 1920x1080 pixels per GPU, aspect kept, same

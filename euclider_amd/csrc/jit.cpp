@@ -8,6 +8,9 @@
 #include <hip/hiprtc.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -594,7 +597,7 @@ static std::string library_cache_dir() {      /* <directory of this shared libra
     return std::string();
 }
 
-int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out) {
+int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out, bool cache_only) {
     if (plan.too_large) {
         out.log = "the scene is too large to specialise (more than " + std::to_string(kJitMaxShapeOps) + " shape operations or " + std::to_string(kJitMaxEntities) +
                   " entities): the interpreter kernels trace it";
@@ -621,6 +624,7 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
             return EU_OK;
         }
     }
+    if (cache_only) { out.log = "not in any cache"; return EU_ERR_BUSY; }
     const auto t0 = std::chrono::steady_clock::now();
     hiprtcProgram prog = nullptr;
     std::vector<const char *> hdr_text, hdr_name;
@@ -662,6 +666,56 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
     std::lock_guard<std::mutex> lk(g_mem_mutex);
     g_mem_cache[fname] = out.code;
     return EU_OK;
+}
+
+/* ------------------------------------------------------------------ asynchronous compilation (EU_SPECIALIZE_ASYNC) */
+namespace {
+struct JitWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<JitJob>> queue;
+    std::thread thread;
+    bool stop = false, started = false;
+    void run() {
+        for (;;) {
+            std::shared_ptr<JitJob> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !queue.empty(); });
+                if (stop) return;
+                job = queue.front();
+                queue.pop_front();
+            }
+            if (job->cancelled.load()) { job->rc = EU_ERR_BUSY; job->done.store(true, std::memory_order_release); continue; }
+            job->plan = jit_generate(*job->flat, job->flags);
+            job->rc = jit_build(job->plan, job->cache_dir, job->build);
+            job->done.store(true, std::memory_order_release);
+        }
+    }
+    ~JitWorker() {      /* process exit / library unload: no new work, and hiprtc is not torn down under the job in progress */
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            queue.clear();
+        }
+        cv.notify_all();
+        if (started && thread.joinable()) thread.join();
+    }
+};
+JitWorker &worker() { static JitWorker w; return w; }
+}  // namespace
+
+std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags) {
+    auto job = std::make_shared<JitJob>();
+    job->flat = std::move(flat); job->cache_dir = cache_dir; job->flags = flags;
+    JitWorker &w = worker();
+    {
+        std::lock_guard<std::mutex> lk(w.mu);
+        if (!w.started) { w.thread = std::thread([&w] { w.run(); }); w.started = true; }
+        w.queue.push_back(job);
+    }
+    w.cv.notify_one();
+    return job;
 }
 
 }  // namespace euclider

@@ -13,6 +13,8 @@
 #ifndef EU_JIT_HPP
 #define EU_JIT_HPP
 
+#include <atomic>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,7 +50,21 @@ struct JitBuild {
 /* Compiles the plan with hiprtc (works without a GPU) or fetches the code object from the cache directories: `cache_dir`
  * (read / write; empty: $XDG_CACHE_HOME/euclider_amd or ~/.cache/euclider_amd) and the read-only directory `jit_cache` next
  * to the library (kernels compiled at build time travel with it).  Returns 0 or a negative EU_ERR_* code (log says why). */
-int jit_build(const JitPlan &plan, const std::string &cache_dir, JitBuild &out);
+int jit_build(const JitPlan &plan, const std::string &cache_dir, JitBuild &out, bool cache_only = false);
+
+/* EU_SPECIALIZE_ASYNC: the compilation runs on a worker thread of this library (one for the process: jobs are served in order) while the
+ * renderer traces with the interpreter kernels; the renderer polls `done` when a frame is launched.  A job whose renderer is gone before
+ * its turn is dropped; the one in progress always finishes (its code object lands in the cache).  At process exit the library waits for
+ * the job in progress (hiprtc must not be torn down under it). */
+struct JitJob {
+    std::shared_ptr<const FlatScene> flat;
+    std::string cache_dir, flags;
+    JitPlan plan;
+    JitBuild build;
+    int rc = 0;
+    std::atomic<bool> done{false}, cancelled{false};
+};
+std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags);
 
 }  // namespace euclider
 

@@ -100,6 +100,7 @@ struct eu_renderer {
     uint32_t jit_hs_cap = 0;
     eu_jit_info jit = {};
     std::string jit_log;
+    std::shared_ptr<euclider::JitJob> jit_job;      /* EU_SPECIALIZE_ASYNC: the compilation in flight, polled when a frame is launched */
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
     static constexpr int WF_MAX_STREAMS = 4;
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
@@ -146,15 +147,9 @@ static void fill_jit_info(const euclider::JitPlan &plan, const euclider::JitBuil
     snprintf(info.key, sizeof info.key, "%s", plan.key.c_str());
 }
 
-/* EU_SPECIALIZE_SYNC: generate, compile (or fetch) and load this scene's kernels; any failure leaves the interpreter kernels in charge */
-static void renderer_attach_jit(eu_renderer *r) {
-    r->jit.requested = 1;
-    const euclider::JitPlan plan = euclider::jit_generate(*r->flat, r->jit_flags);
-    euclider::JitBuild b;
-    const int rc = euclider::jit_build(plan, r->cache_dir, b);
-    r->jit_log = b.log;
+/* load a specialised code object and switch the renderer to its kernels */
+static void renderer_load_jit(eu_renderer *r, const euclider::JitPlan &plan, const euclider::JitBuild &b) {
     fill_jit_info(plan, b, false, r->jit);
-    if (rc != EU_OK) return;
     if (hipModuleLoadData(&r->jit_module, b.code.data()) != hipSuccess) { (void)hipGetLastError(); r->jit_module = nullptr; r->jit_log += "\nhipModuleLoadData failed"; return; }
     if (hipModuleGetFunction(&r->jit_intersect, r->jit_module, "eu_jit_intersect") != hipSuccess ||
         hipModuleGetFunction(&r->jit_shade, r->jit_module, "eu_jit_shade") != hipSuccess ||
@@ -173,8 +168,33 @@ static void renderer_attach_jit(eu_renderer *r) {
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, r->jit_shade, EU_WF_BLOCK, 0) == hipSuccess &&
         hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, r->jit_shade0, EU_WF_BLOCK, 0) == hipSuccess) {
         const int o = occ < occ0 ? occ : occ0;
-        r->wf_seg_per_cu = o >= 4 ? 4u : (o >= 3 ? 3u : (o >= 2 ? 2u : 1u));
+        const uint32_t per_cu = o >= 4 ? 4u : (o >= 3 ? 3u : (o >= 2 ? 2u : 1u));
+        if (per_cu != r->wf_seg_per_cu) { r->wf_seg_per_cu = per_cu; r->wf_pixels = 0; }      /* (the queues are cut anew at the next frame) */
     } else (void)hipGetLastError();
+}
+
+/* EU_SPECIALIZE_SYNC: generate, compile (or fetch) and load this scene's kernels; any failure leaves the interpreter kernels in charge.
+ * EU_SPECIALIZE_ASYNC: a code object already in a cache is loaded at once, otherwise the compilation goes to the library's worker thread
+ * and renderer_poll_jit switches over when it is done. */
+static void renderer_attach_jit(eu_renderer *r, bool async) {
+    r->jit.requested = 1;
+    const euclider::JitPlan plan = euclider::jit_generate(*r->flat, r->jit_flags);
+    euclider::JitBuild b;
+    const int rc = euclider::jit_build(plan, r->cache_dir, b, async);
+    r->jit_log = b.log;
+    fill_jit_info(plan, b, false, r->jit);
+    if (rc == EU_OK) { renderer_load_jit(r, plan, b); return; }
+    if (async && rc == EU_ERR_BUSY) r->jit_job = euclider::jit_submit(r->flat, r->cache_dir, r->jit_flags);
+}
+
+static void renderer_poll_jit(eu_renderer *r) {
+    if (!r->jit_job || !r->jit_job->done.load(std::memory_order_acquire)) return;
+    std::shared_ptr<euclider::JitJob> job = r->jit_job;
+    r->jit_job.reset();
+    r->jit_log = job->build.log;
+    if (job->rc != EU_OK) { fill_jit_info(job->plan, job->build, false, r->jit); return; }
+    (void)hipDeviceSynchronize();      /* frames in flight still run the interpreter kernels on these buffers */
+    renderer_load_jit(r, job->plan, job->build);
 }
 
 static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_scene, int device, const eu_renderer_opts *opts_in, eu_renderer **out, char *err, size_t errlen) {
@@ -201,7 +221,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
     auto failhip = [&](int code) { set_err(err, errlen, r->err); eu_renderer_destroy(r); return code; };
     if (h.hit_cap > 96) { r->err = "scene needs a per-ray hit stack of " + std::to_string(h.hit_cap) + " entries (compiled maximum 96)"; return failhip(EU_ERR_CAPACITY); }
     if (h.list_depth > 8 || h.color_depth > 4 || h.rpn_depth > 8) { r->err = "scene exceeds a compiled stack depth (csg lists 8, colour 4, rpn 8)"; return failhip(EU_ERR_CAPACITY); }
-    if (r->opts.kernel > EU_KERNEL_STACK || r->opts.specialize > EU_SPECIALIZE_SYNC || r->opts.streams > (uint32_t)eu_renderer::WF_MAX_STREAMS ||
+    if (r->opts.kernel > EU_KERNEL_STACK || r->opts.specialize > EU_SPECIALIZE_ASYNC || r->opts.streams > (uint32_t)eu_renderer::WF_MAX_STREAMS ||
         !(r->opts.ray_factor >= 0.0)) { r->err = "bad eu_renderer_opts"; return failhip(EU_ERR_INVALID_ARGUMENT); }
     auto body = [&]() -> int {
         HIP_TRY(hipSetDevice(device));
@@ -229,7 +249,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         uint32_t specialize = r->opts.specialize;
 #ifdef EU_DIAGNOSTICS      /* profiling scripts only: the shipped library reads no environment variable here */
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega" && std::string(k) != "stack";
-        if (const char *k = getenv("EU_SPECIALIZE")) specialize = std::string(k) == "sync" ? EU_SPECIALIZE_SYNC : EU_SPECIALIZE_OFF;
+        if (const char *k = getenv("EU_SPECIALIZE")) specialize = std::string(k) == "sync" ? EU_SPECIALIZE_SYNC : (std::string(k) == "async" ? EU_SPECIALIZE_ASYNC : EU_SPECIALIZE_OFF);
         if (const char *k = getenv("EU_WF_RAY_FACTOR")) r->wf_ray_factor = (real)atof(k);
         if (const char *k = getenv("EU_WF_BAND_PIXELS")) r->wf_band_pixels = strtoull(k, nullptr, 10);
         if (const char *k = getenv("EU_WF_STREAMS")) { int v = atoi(k); r->wf_n_streams = v < 1 ? 1 : (v > eu_renderer::WF_MAX_STREAMS ? eu_renderer::WF_MAX_STREAMS : v); }
@@ -241,7 +261,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         HIP_TRY(hipDeviceSynchronize());      /* (hipMemset is asynchronous to the host; see wf_ensure) */
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
-        if (specialize == EU_SPECIALIZE_SYNC && r->use_wavefront) renderer_attach_jit(r);
+        if ((specialize == EU_SPECIALIZE_SYNC || specialize == EU_SPECIALIZE_ASYNC) && r->use_wavefront) renderer_attach_jit(r, specialize == EU_SPECIALIZE_ASYNC);
         return EU_OK;
     };
     int rc = body();
@@ -269,6 +289,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
+    if (r->jit_job) r->jit_job->cancelled.store(true);      /* (dropped if its turn has not come; the worker keeps its own reference to the scene) */
     if (r->jit_module) (void)hipModuleUnload(r->jit_module);
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
@@ -530,6 +551,7 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     df.time_s = (real)f->time_ms / R(1000.0);
     if (single) { df.strip_count = 0; df.local_rows = 1; df.single_pixel = 1; df.single_x = single_x; df.single_y = f->row_begin; df.tiles_x = 1; df.n_tiles = 1; }
     if (rows == 0) return EU_OK;
+    renderer_poll_jit(r);
     if (r->prepare_only) {
         if (r->use_wavefront) return (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
         return EU_OK;

@@ -98,7 +98,8 @@ class Environment:
 
     # How renderers are created (eu_renderer_opts): set before the first render.
     #   specialize: "off" (the ahead-of-time kernels interpret the flat scene), "sync" (kernels specialised for this scene are compiled
-    #               with hiprtc when the renderer is created, a few seconds the first time, cached on disk), None = the library default
+    #               with hiprtc when the renderer is created, a few seconds the first time, cached on disk), "async" (the same on a worker
+    #               thread: frames use the interpreter kernels until the code object is ready), None = the library default
     #   kernel: None / "wavefront" / "stack";  streams, ray_factor, band_pixels: 0 = default;  shade_scene_global: test hook
     def configure(self, specialize=None, kernel=None, streams=0, ray_factor=0.0, band_pixels=0, cache_dir=None, shade_scene_global=False,
                   jit_flags=None, flags=0):
@@ -111,7 +112,8 @@ class Environment:
     def _renderer_opts(self):
         o = dict(DEFAULT_RENDERER_OPTS)
         o.update({k: v for k, v in getattr(self, "_opts", {}).items() if v not in (None, 0, 0.0, False)})
-        spec = {None: _capi.EU_SPECIALIZE_AUTO, "auto": _capi.EU_SPECIALIZE_AUTO, "off": _capi.EU_SPECIALIZE_OFF, "sync": _capi.EU_SPECIALIZE_SYNC}[o.get("specialize")]
+        spec = {None: _capi.EU_SPECIALIZE_AUTO, "auto": _capi.EU_SPECIALIZE_AUTO, "off": _capi.EU_SPECIALIZE_OFF, "sync": _capi.EU_SPECIALIZE_SYNC,
+                "async": _capi.EU_SPECIALIZE_ASYNC}[o.get("specialize")]
         kern = {None: _capi.EU_KERNEL_AUTO, "wavefront": _capi.EU_KERNEL_WAVEFRONT, "stack": _capi.EU_KERNEL_STACK}[o.get("kernel")]
         cache = o.get("cache_dir")
         flags = o.get("jit_flags")

@@ -127,6 +127,10 @@ int eu_device_count(void);
 #define EU_SPECIALIZE_SYNC 2u      /* eu_renderer_create compiles trace kernels specialised for THIS scene with hiprtc (a few seconds the
                                       first time; the code object is cached on disk by content) and every frame uses them; if the compilation
                                       fails the renderer falls back to the interpreter kernels and eu_renderer_jit_info says so */
+#define EU_SPECIALIZE_ASYNC 3u     /* the same without the wait: a worker thread of the library compiles while the renderer traces with the
+                                      interpreter kernels, and switches to the specialised ones at the first frame launched after the code object
+                                      is ready (eu_renderer_jit_info.active turns 1).  The frames are the same bit for bit either way.  A code
+                                      object already in a cache is used from the first frame on. */
 #define EU_RENDERER_SHADE_SCENE_GLOBAL 1u   /* flags: the interpreter's shade kernel reads the scene from global memory, not from its LDS copy
                                                (what scenes above ~40 KB get anyway; here so that tests can reach that variant) */
 typedef struct {

@@ -84,3 +84,43 @@ def test_sequence_and_trace_screen_point_on_specialised_kernels(scene, depth):
     assert all(np.array_equal(f.data, ref.data) and f.stats == ref.stats for f in frames)
     assert [b.trace_screen_point(0.0, depth, x, y, 192, 108) for (x, y) in ((0, 0), (95, 54), (191, 107))] == pts
     b.close()
+
+
+def test_asynchronous_specialisation(tmp_path):
+    """EU_SPECIALIZE_ASYNC: the renderer is usable at once (interpreter kernels), switches to the specialised kernels at a frame boundary
+    when the worker thread's compilation is done, and every frame on either side of the switch is the same."""
+    import time
+    from euclider_amd import Parser
+    text = open(os.path.join(SCENES, "3d_fresnel_2.json")).read().replace("1.458", "1.4453125")      # a scene no cache knows yet
+    cache = str(tmp_path / "cache")
+    ref_env = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="off")
+    ref = ref_env.render((128, 128))
+    ref_env.close()
+    env = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="async", cache_dir=cache)
+    t0 = time.time()
+    first = env.render((128, 128))
+    created_and_first_frame_s = time.time() - t0
+    info = env.jit_info()
+    assert info["requested"]
+    frames_before = frames_after = 0
+    while time.time() - t0 < 180:
+        img = env.render((128, 128))
+        assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
+        if env.jit_info()["active"]:
+            frames_after += 1
+            if frames_after >= 3:
+                break
+        else:
+            frames_before += 1
+            time.sleep(0.05)
+    assert np.array_equal(first.data, ref.data)
+    assert env.jit_info()["active"], "the worker thread's compilation never arrived"
+    assert frames_before >= 1 or created_and_first_frame_s < 1.0      # the compilation did not block the first frames
+    env.close()
+    again = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="async", cache_dir=cache)      # now cached: specialised from the first frame on
+    img = again.render((128, 128))
+    assert again.jit_info()["active"] and again.jit_info()["from_cache"] and np.array_equal(img.data, ref.data)
+    again.close()
+    gone = Parser(texture_dirs=[ROOT]).parse(text.replace("1.4453125", "1.44921875")).configure(specialize="async", cache_dir=cache)
+    gone.render((64, 64))
+    gone.close()          # destroyed while its compilation is queued or running: nothing may crash, here or at interpreter exit

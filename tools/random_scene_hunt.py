@@ -13,7 +13,7 @@ SPEC = os.environ.get("HUNT_SPECIALIZE", "off")      # "sync": kernels specialis
 not_specialised = 0
 bad = []; undefined = 0; skipped = 0
 for seed in range(lo, hi):
-    if seed % 200 == 0: print("at seed", seed, "bad so far", len(bad), flush=True)
+    if seed % (10 if SPEC == "sync" else 200) == 0: print("at seed", seed, "bad so far", len(bad), flush=True)
     text, dim = random_scene(seed)
     try:
         osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if F32 else "")
