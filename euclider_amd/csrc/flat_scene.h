@@ -77,7 +77,7 @@ struct EuFlatHeader {
     uint32_t n_color_ops, off_color_ops;     /* EuFlatColorOp, 16 words each */
     uint32_t n_mapped, off_mapped;           /* EuFlatMapped, 8 words each */
     uint32_t n_perlin, off_perlin;           /* 64 words (512 B permutation) each */
-    uint32_t background, hit_cap;            /* background mapped-texture id; per-ray hit-stack entries needed */
+    uint32_t background, hit_cap;            /* background mapped-texture id; per-ray hit-stack entries: bits 0..15 what the wavefront kernels reserve, bits 16..31 the strict worst case (scene_host.cpp: HitUse) */
     uint32_t list_depth, color_depth;        /* max simultaneous hit lists / colour stack depth */
     uint32_t rpn_depth, flags;
     uint32_t n_params, off_params;           /* leaf parameter doubles */

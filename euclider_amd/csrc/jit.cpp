@@ -144,7 +144,10 @@ struct Gen {
     /* Shape parameters and bounding spheres are NOT emitted as constants: they are read from the resident scene at constant offsets
      * (wave-uniform addresses: scalar loads with immediate offsets).  As literals every double costs two s_mov_b32 and the optimiser,
      * seeing through them, reshapes the chain matrices into hundreds of simultaneously live lane masks (measured: 166 VGPRs + 115
-     * spilled, 533 SGPR spills for 3d_room's intersect kernel against 105 / 47 with the parameters in memory). */
+     * spilled, 533 SGPR spills for 3d_room's intersect kernel against 105 / 47 with the parameters in memory).  The same holds for
+     * the few numbers the closed-form box routines need (chain_slab, chain_inside_box), tried on their own in round 3: with them
+     * visible the optimiser shares plane hits between 4d_frame's concentric boxes and keeps them all alive -- 912 SGPR spills,
+     * 2.6 against 3.9 Gray/s. */
     bool shape_params_in_memory = true;
     std::string op_params(const std::string &name, uint32_t i) const {
         const OpView p = op(i);
@@ -363,7 +366,7 @@ struct Gen {
         /* ---- trace_closest ---- */
         Out tc;
         tc.f("    /* trace_closest (universe/mod.rs:85-147): every surfaced entity's shape program as a straight line */\n");
-        tc.f("    template <class HS>\n    static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, bool use_box, bool &fail,\n"
+        tc.f("    template <class HS>\n    static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, int use_box, bool &fail,\n"
              "                                     bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {\n");
         for (uint32_t e = 0; e < ne; e++) {
             const EntityView E = entity(e);
@@ -527,8 +530,9 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
     plan.dim = (int)h.dim;
     /* the per-lane hit stack: in LDS while three workgroups per CU still fit (4 waves x cap x 64 lanes x (sizeof(real) + 4) bytes each),
      * else a private array of exactly the entries this scene needs (the ahead-of-time kernels only have 16 and 96) */
-    const uint32_t cap = h.hit_cap < 8 ? 8u : ((h.hit_cap + 3u) & ~3u);
-    plan.hs_lds = h.hit_cap <= 32;
+    const uint32_t soft_cap = h.hit_cap & 0xffffu;      /* (bits 16..: the strict bound of the stack kernels, flat_scene.h) */
+    const uint32_t cap = soft_cap < 8 ? 8u : ((soft_cap + 3u) & ~3u);
+    plan.hs_lds = soft_cap <= 32;
     plan.hs_cap = cap;
     plan.too_large = h.n_ops > kJitMaxShapeOps || h.n_entities > kJitMaxEntities;
     Gen g(flat);

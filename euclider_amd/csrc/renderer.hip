@@ -71,7 +71,7 @@ struct eu_renderer {
     std::string cache_dir, jit_flags;
     int device = 0;
     int dim = 3;
-    uint32_t hit_cap = 0;
+    uint32_t hit_cap = 0, hit_cap_strict = 0;      /* hit-stack entries the wavefront kernels reserve / the strict worst case of the stack kernels (scene_host.cpp: HitUse) */
     uint32_t color_depth = 0;
     uint32_t scene_words = 0;
     uint64_t *d_scene = nullptr;
@@ -216,10 +216,11 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
     }
     const EuFlatHeader &h = flat_scene->header();
     r->dim = (int)h.dim;
-    r->hit_cap = h.hit_cap;
+    r->hit_cap = h.hit_cap & 0xffffu;
+    r->hit_cap_strict = h.hit_cap >> 16;
     r->color_depth = h.color_depth;
     auto failhip = [&](int code) { set_err(err, errlen, r->err); eu_renderer_destroy(r); return code; };
-    if (h.hit_cap > 96) { r->err = "scene needs a per-ray hit stack of " + std::to_string(h.hit_cap) + " entries (compiled maximum 96)"; return failhip(EU_ERR_CAPACITY); }
+    if (r->hit_cap_strict > 96) { r->err = "scene needs a per-ray hit stack of " + std::to_string(r->hit_cap_strict) + " entries (compiled maximum 96)"; return failhip(EU_ERR_CAPACITY); }
     if (h.list_depth > 8 || h.color_depth > 4 || h.rpn_depth > 8) { r->err = "scene exceeds a compiled stack depth (csg lists 8, colour 4, rpn 8)"; return failhip(EU_ERR_CAPACITY); }
     if (r->opts.kernel > EU_KERNEL_STACK || r->opts.specialize > EU_SPECIALIZE_ASYNC || r->opts.streams > (uint32_t)eu_renderer::WF_MAX_STREAMS ||
         !(r->opts.ray_factor >= 0.0)) { r->err = "bad eu_renderer_opts"; return failhip(EU_ERR_INVALID_ARGUMENT); }
@@ -332,7 +333,7 @@ static int make_dev_camera(const eu_camera *cam, const eu_frame *f, EuDevCamera 
 template <int D, int HSCAP, bool LDS>
 static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCamera &dc, const EuDevFrame &df, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
     auto kern = eu_trace_kernel<D, HSCAP, LDS>;
-    const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u));
+    const uint32_t hs_cap = HSCAP ? (uint32_t)HSCAP : (r->hit_cap_strict < 8 ? 8u : ((r->hit_cap_strict + 3u) & ~3u));
     size_t lds_bytes = LDS ? (size_t)r->scene_words * 8 : 0;
     if (HSCAP == 0) lds_bytes += (size_t)(EU_BLOCK / 64) * hs_cap * 64 * 12;
     int blocks_per_cu = 0;
@@ -565,7 +566,7 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
         if (rc != EU_OK) return rc;
     } else {
         /* hit stack in LDS when the scene's static bound is small (16 entries * 12 B * 256 lanes = 48 KB per block) */
-        const bool hs_lds = r->hit_cap <= 32 && r->scene_in_lds;
+        const bool hs_lds = r->hit_cap_strict <= 32 && r->scene_in_lds;
         if (r->dim == 3) {
             if (hs_lds) e = launch_trace<3, 0, true>(r, stream, dc, df, rgba, hit_t, point);
             else if (r->scene_in_lds) e = launch_trace<3, 96, true>(r, stream, dc, df, rgba, hit_t, point);
@@ -1084,7 +1085,7 @@ extern "C" int eu_trace_path(eu_renderer *r, const eu_f64 location[4], const eu_
                              eu_f64 out_location[4], eu_f64 out_direction[4], int32_t *found) {
     if (!r || !location || !direction || !out_location || !out_direction || !found) return EU_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
-    if (r->hit_cap > 96) { r->err = "scene needs a deeper hit stack than the path kernel has (96)"; return EU_ERR_CAPACITY; }
+    if (r->hit_cap_strict > 96) { r->err = "scene needs a deeper hit stack than the path kernel has (96)"; return EU_ERR_CAPACITY; }
     if (!r->d_path_in) {
         HIP_TRY(hipMalloc((void **)&r->d_path_in, 9 * sizeof(real)));
         HIP_TRY(hipMalloc((void **)&r->d_path_out, sizeof(EuPathResult)));

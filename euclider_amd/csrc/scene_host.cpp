@@ -728,7 +728,14 @@ struct Flattener {
     std::vector<std::shared_ptr<Texture>> textures;
     std::vector<std::array<uint8_t, 512>> perlin;
     std::map<const void *, uint32_t> mat_ids, surf_ids, mapped_ids;
-    uint32_t hit_cap = 0, list_depth = 0, color_depth = 0, rpn_depth = 0, n_leaves = 0;
+    uint32_t hit_cap = 0, hit_cap_strict = 0, list_depth = 0, color_depth = 0, rpn_depth = 0, n_leaves = 0;
+    /* Hit-stack entries, counted twice.  `strict` is the worst case whatever the arithmetic does: a chain of n half-spaces may in
+     * principle emit n hits.  `soft` is what the wavefront kernels reserve: an Intersection chain is a convex solid and a line meets
+     * its boundary at most twice, so its stream has at most two elements unless rounding noise among near-tied plane hits lets
+     * a third through.  A kernel that meets such a ray (its stack fills up: push_chain, csg_merge) raises EuDevCounters::overflow and
+     * the frame is traced again by the stack kernel, whose hit stack has the strict size: exact either way, and 4d_frame's stack
+     * (strict 80 entries, soft 20) moves from scratch memory into LDS. */
+    struct HitUse { uint32_t soft, strict; };
 
     static bool is_flat_leaf(const Shape &s) { return s.kind == Shape::HalfSpace || s.kind == Shape::Hyperplane; }
 
@@ -778,11 +785,12 @@ struct Flattener {
 
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
     static bool no_guards() { static const bool v = getenv("EU_NO_SKIP_OPS") != nullptr; return v; }      /* A/B diagnostics */
-    uint32_t emit_shape(const Shape &s, uint32_t base_use, uint32_t depth, bool is_root = false, real parent_r = INFINITY) {
+    HitUse emit_shape(const Shape &s, HitUse base_use, uint32_t depth, bool is_root = false, real parent_r = INFINITY) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
         op.first = (uint16_t)ops.size();
-        uint32_t len = 0;
+        HitUse len{0, 0};
+        auto note = [&](HitUse use) { if (use.soft > hit_cap) hit_cap = use.soft; if (use.strict > hit_cap_strict) hit_cap_strict = use.strict; };
         std::vector<const Shape *> chain;
         if (s.kind == Shape::ComposableShape && (s.operation == SetOperation::Union || s.operation == SetOperation::Intersection) &&
             collect_chain(s, s.operation, chain) && chain.size() >= 2 && chain.size() <= EU_CHAIN_MAX) {
@@ -803,9 +811,14 @@ struct Flattener {
                 params.push_back(ok ? EU_BOUND_FAR2 * rr * rr : R(0.0));
             }
             n_leaves += (uint32_t)chain.size();
-            len = (uint32_t)chain.size();
-            uint32_t use = base_use + 2 * len;               /* the list + slots for the t_k (picked by run-time index) */
-            if (use > hit_cap) hit_cap = use;
+            const uint32_t cn = (uint32_t)chain.size();
+            if (s.operation == SetOperation::Intersection) {  /* the list only (its t are picked out of registers: chain_pick_t) */
+                len = HitUse{cn < 2u ? cn : 2u, cn};
+                note(HitUse{base_use.soft + len.soft, base_use.strict + len.strict});
+            } else {                                          /* the list + slots for the t_k (picked by run-time index) */
+                len = HitUse{cn, cn};
+                note(HitUse{base_use.soft + 2 * cn, base_use.strict + 2 * cn});
+            }
             if (depth + 1 > list_depth) list_depth = depth + 1;
         } else if (s.kind == Shape::ComposableShape) {
             /* a bounded subtree whose sphere is clearly smaller than what encloses it gets a guard op in front (EU_SH_SKIP) */
@@ -822,8 +835,8 @@ struct Flattener {
                 }
             }
             const real child_r = has_b ? std::min(parent_r, (real)sb_.r) : parent_r;
-            uint32_t la = emit_shape(*s.sa, base_use, depth, false, child_r);
-            uint32_t lb = emit_shape(*s.sb, base_use + la, depth + 1, false, child_r);
+            const HitUse la = emit_shape(*s.sa, base_use, depth, false, child_r);
+            const HitUse lb = emit_shape(*s.sb, HitUse{base_use.soft + la.soft, base_use.strict + la.strict}, depth + 1, false, child_r);
             if (skip_at != (size_t)-1) {
                 if (ops.size() >= 65535) fail(ParserError::CustomError, "too many shape nodes");
                 ops[skip_at].first = (uint16_t)ops.size();        /* index the subtree's root op is about to get */
@@ -832,9 +845,9 @@ struct Flattener {
             /* a Complement may hand out `a` once more without consuming it (shape.rs:390-392): one element more than it
              * consumed.  At an entity's root only element 0 is ever looked at, so the extra slot is not reserved there. */
             const uint32_t extra = s.operation == SetOperation::Complement ? 1u : 0u;
-            len = la + lb + extra;
-            uint32_t use = base_use + la + lb + la + lb + (is_root ? 0u : extra);       /* inputs + merge output */
-            if (use > hit_cap) hit_cap = use;
+            len = HitUse{la.soft + lb.soft + extra, la.strict + lb.strict + extra};
+            note(HitUse{base_use.soft + 2 * (la.soft + lb.soft) + (is_root ? 0u : extra),       /* inputs + merge output */
+                        base_use.strict + 2 * (la.strict + lb.strict) + (is_root ? 0u : extra)});
             if (depth + 2 > list_depth) list_depth = depth + 2;
             op.kind = (uint8_t)(EU_SH_UNION + (int)s.operation);
             op.param = 0;
@@ -842,30 +855,29 @@ struct Flattener {
             n_leaves++;
             op.param = (uint32_t)params.size();
             switch (s.kind) {
-            case Shape::VoidShape: op.kind = EU_SH_VOID; len = 0; break;
+            case Shape::VoidShape: op.kind = EU_SH_VOID; len = HitUse{0, 0}; break;
             case Shape::Sphere:
-                op.kind = EU_SH_SPHERE; len = 2;
+                op.kind = EU_SH_SPHERE; len = HitUse{2, 2};
                 for (int i = 0; i < D; i++) params.push_back(s.a[i]);
                 params.push_back(s.r); params.push_back(s.r * s.r);
                 break;
             case Shape::Hyperplane:
-                op.kind = EU_SH_PLANE; len = 1;
+                op.kind = EU_SH_PLANE; len = HitUse{1, 1};
                 for (int i = 0; i < D; i++) params.push_back(s.a[i]);
                 params.push_back(s.r);
                 break;
             case Shape::HalfSpace:
-                op.kind = EU_SH_HALFSPACE; len = 1;
+                op.kind = EU_SH_HALFSPACE; len = HitUse{1, 1};
                 push_halfspace_params(s);
                 break;
             default:
-                op.kind = EU_SH_CYLINDER; len = 2;
+                op.kind = EU_SH_CYLINDER; len = HitUse{2, 2};
                 for (int i = 0; i < D; i++) params.push_back(s.a[i]);
                 for (int i = 0; i < D; i++) params.push_back(s.b[i]);
                 params.push_back(s.r); params.push_back(s.r * s.r);
                 break;
             }
-            uint32_t use = base_use + len;
-            if (use > hit_cap) hit_cap = use;
+            note(HitUse{base_use.soft + len.soft, base_use.strict + len.strict});
             if (depth + 1 > list_depth) list_depth = depth + 1;
         }
         if (ops.size() >= 65535) fail(ParserError::CustomError, "too many shape nodes");
@@ -1128,7 +1140,7 @@ FlatScene flatten(const Universe &u) {
         fe.shape_first = (uint16_t)f.ops.size();
         {
             const auto eb = f.shape_bound(*e->shape);
-            f.emit_shape(*e->shape, 0, 0, true, eb.ok && eb.r > R(0.0) ? (real)eb.r : (real)INFINITY);
+            f.emit_shape(*e->shape, Flattener::HitUse{0, 0}, 0, true, eb.ok && eb.r > R(0.0) ? (real)eb.r : (real)INFINITY);
         }
         fe.shape_root = (uint16_t)(f.ops.size() - 1);
         fe.max_hits = f.hit_cap;
@@ -1167,7 +1179,7 @@ FlatScene flatten(const Universe &u) {
     h.n_mapped = (uint32_t)f.mapped.size(); h.off_mapped = append(f.mapped.data(), f.mapped.size() * sizeof(EuFlatMapped));
     h.n_perlin = (uint32_t)f.perlin.size(); h.off_perlin = append(f.perlin.data(), f.perlin.size() * 512);
     h.n_bounds = (uint32_t)(f.bounds.size() / (size_t)(u.dim + 2)); h.off_bounds = append(f.bounds.data(), f.bounds.size() * sizeof(f.bounds[0]));
-    h.background = bg; h.hit_cap = f.hit_cap; h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
+    h.background = bg; h.hit_cap = f.hit_cap | (f.hit_cap_strict << 16); h.list_depth = f.list_depth; h.color_depth = f.color_depth; h.rpn_depth = f.rpn_depth;
     /* flags bit 1: some shape program holds guard ops (EU_SH_SKIP) */
     for (auto &o : f.ops) if (o.kind == EU_SH_SKIP) { h.flags |= 2u; break; }
     /* flags bit 0: some surface can spawn BOTH a transmission and a reflection ray (ratio strictly between 0 and 1
@@ -1180,7 +1192,7 @@ FlatScene flatten(const Universe &u) {
     out.info.dim = u.dim;
     out.info.n_entities = h.n_entities; out.info.n_shape_ops = h.n_ops; out.info.n_leaves = f.n_leaves;
     out.info.n_materials = h.n_materials; out.info.n_surfaces = h.n_surfaces; out.info.n_color_ops = h.n_color_ops;
-    out.info.n_textures = h.n_mapped; out.info.hit_cap = h.hit_cap; out.info.list_depth = h.list_depth;
+    out.info.n_textures = h.n_mapped; out.info.hit_cap = f.hit_cap_strict; out.info.list_depth = h.list_depth;
     out.info.flat_bytes = h.n_words * 8;
     return out;
 }

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(EU_BLOCK) void eu_trace_kernel(const uint64_t *__re
         v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
     if ((threadIdx.x & 63) == 0) {
+        v3 = (v3 & 0x3fffffffull) + (v3 >> 30);      /* (EU_CNT_HS_FULL cannot happen on this kernel's strict-size stack; were it to, it is reported) */
         if (v0) atomicAdd(&counters->rays, v0);
         if (v1) atomicAdd(&counters->bg_samples, v1);
         if (v2) atomicAdd(&counters->nan_pixels, v2);

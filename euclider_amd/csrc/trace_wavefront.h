@@ -97,6 +97,8 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
         v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
     if ((threadIdx.x & 63) == 0) {
+        if (v3 >> 30) atomicAdd(&counters->overflow, v3 >> 30);      /* lanes whose hit stack was full (EU_CNT_HS_FULL): the frame is traced again */
+        v3 &= 0x3fffffffull;
         if (v0) atomicAdd(&wg_cnt[0], v0);
         if (v1) atomicAdd(&wg_cnt[1], v1);
         if (v2) atomicAdd(&wg_cnt[2], v2);
@@ -316,23 +318,30 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
             }
             SHP(cnt, 9);      /* per batch: current ray out of the prefetch registers, next ray located and requested */
             if (live) {
-            /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  A wave whose rays are
-             * all regular (finite, no zero direction component) evaluates box chains with one product per dot product
-             * (chain_matrices_box); should a lane then report a non-finite hit point, the wave's rays are traced once more the generic way. */
+            /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum.  Box chains are answered
+             * in closed form (chain_slab), and where that refuses a ray (a near-tie of two plane hits, an origin in a face plane, a
+             * NaN ray) by the generic chain routine at once: eval_chain. */
             bool have = false;
             real best_t = R(0.0);
             uint32_t best_code = 0, best_ent = EU_WF_ENT_MISS;
             if (trace_any) {
                 cnt.rays++;
-                bool use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull;
+#ifdef EU_NO_SLAB     /* A/B diagnostic (bench.py --jit-flags=-DEU_NO_SLAB), round 2's route: a wave whose rays are all regular (finite, no zero
+                       * direction component) evaluates box chains with one product per dot product (chain_matrices_box); should a lane then
+                       * report a non-finite hit point, the wave's rays are traced once more the generic way */
+                int use_box = __ballot(!ray_is_regular<D>(o, d)) == 0ull ? 1 : 0;
                 for (;;) {
                     bool fail = false;
                     LaneCounters c1 = cnt;
                     have = false; best_t = R(0.0); best_code = 0; best_ent = EU_WF_ENT_MISS;
                     P::trace_closest(S, o, d, HS, c1, use_box, fail, have, best_t, best_code, best_ent);
                     if (__ballot(fail) == 0ull) { cnt = c1; break; }
-                    use_box = false;
+                    use_box = 0;
                 }
+#else
+                bool fail = false;      /* (only set on the route above) */
+                P::trace_closest(S, o, d, HS, cnt, 2, fail, have, best_t, best_code, best_ent);
+#endif
             }
             {
                 EuWfHit h;

@@ -124,3 +124,31 @@ def test_asynchronous_specialisation(tmp_path):
     gone = Parser(texture_dirs=[ROOT]).parse(text.replace("1.4453125", "1.44921875")).configure(specialize="async", cache_dir=cache)
     gone.render((64, 64))
     gone.close()          # destroyed while its compilation is queued or running: nothing may crash, here or at interpreter exit
+
+
+@pytest.mark.parametrize("scene,depth", [("4d_frame.json", 6), ("3d_room.json", 5)])
+def test_full_hit_stack_retraces_the_frame(scene, depth, tmp_path):
+    """The wavefront kernels reserve two hit-stack entries for an Intersection chain (a line meets a convex solid's boundary twice);
+    should rounding noise ever let a third hit through, the lane reports a full stack, the frame counts as overflowed and the stack
+    kernel -- whose stack has the strict size -- traces it again.  -DEU_TEST_HS_FULL makes every box that is hit report that:
+    the frame must still be the interpreter's, and the slow path must be visible (eu_renderer_retraces)."""
+    from euclider_amd import Parser
+    path = os.path.join(SCENES, scene)
+    def place(env):      # (4d_frame's own camera sits inside all of its boxes: one hit each)
+        env.camera.max_depth = depth
+        if scene.startswith("4d"):
+            for k, x in enumerate((-10.0, 0.5, 0.25, 0.0)):
+                env.camera.location[k] = x
+    good = Parser().parse_file(path).configure(specialize="off")
+    place(good)
+    ref = good.render((160, 90), want_hit_t=True)
+    assert good.retraces() == 0
+    good.close()
+    env = Parser().parse_file(path).configure(specialize="sync", cache_dir=str(tmp_path), jit_flags="-DEU_TEST_HS_FULL")
+    place(env)
+    img = env.render((160, 90), want_hit_t=True)
+    assert env.jit_info()["active"] and env.retraces() == 1
+    env.close()
+    assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
+    both_nan = np.isnan(img.hit_t) & np.isnan(ref.hit_t)
+    assert np.array_equal(img.hit_t[~both_nan], ref.hit_t[~both_nan])

@@ -254,3 +254,55 @@ def test_box_with_faces_through_coordinate_planes(low_precision):
         both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
         assert np.array_equal(img.hit_t[~both_nan], ohit[~both_nan])
     env.close()
+
+
+@pytest.mark.parametrize("low_precision", [False, True])
+@pytest.mark.parametrize("dim", [3, 4])
+def test_box_rays_with_tied_plane_hits(dim, low_precision):
+    """Axis-aligned cameras on the symmetry axes of cuboids / hypercuboids, outside and at the centre, odd and even frames: whole
+    diagonals of pixels whose rays meet two face planes at exactly the same t, pass through edges and corners, or run inside a
+    face plane.  Those are the rays the closed-form slab answer for boxes (chain_slab) must hand back to the cascade (its
+    all-pairs separation test), so the frames must still equal the oracle's bit for bit."""
+    import json
+    from euclider_amd import Parser
+    from oracle.scene_loader import OracleScene, default_texture_loader
+
+    if dim == 3:
+        def glass(shape):
+            return {"Entity3Impl::new_with_surface": [shape, {"Vacuum3::new": []}, {"ComposableSurface3": {
+                "reflection_ratio": {"reflection_ratio_fresnel_3": [1.458, 1]},
+                "reflection_direction": {"reflection_direction_specular_3": []},
+                "threshold_direction": {"threshold_direction_snell_3": [1.458]},
+                "surface_color": {"surface_color_uniform_3": [{"Rgba::new": [0.2, 0.4, 0.1, 0.3]}]}}}]}
+        text = json.dumps({"Universe3": {"camera": {"FreeCamera3": []}, "entities": [
+            glass({"HalfSpace3::cuboid": [{"Point3::new": [5, 0, 0]}, {"Vector3::new": [2, 2, 2]}]}),
+            glass({"ComposableShape3::of": [[{"HalfSpace3::cuboid": [{"Point3::new": [-6, 0, 0]}, {"Vector3::new": [4, 4, 4]}]},
+                                             {"HalfSpace3::cuboid": [{"Point3::new": [-6, 0, 0]}, {"Vector3::new": [6, 2, 2]}]}],
+                                            {"SetOperation": ["Complement"]}]}),
+            {"Void3::new_with_vacuum": []}],
+            "background": {"MappedTextureImpl3::new": [{"uv_sphere_3": [{"Point3::new": [0, 0, 0]}]},
+                                                      {"texture_image_nearest_neighbor": ["./resources/simple.png"]}]}}})
+        poses = [([0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]), ([0, 0, 0], [-1, 0, 0], [0, -1, 0], [0, 0, 1]),
+                 ([5, 0, 0], [0, 1, 0], [-1, 0, 0], [0, 0, 1]), ([5, 1, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]),
+                 ([5, 0, 8], [0, 0, -1], [0, 1, 0], [1, 0, 0])]
+    else:
+        text = open(os.path.join(ROOT, "scenes", "4d_frame.json")).read()
+        poses = [([-10, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]), ([0, 0, 0, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 1, 0]),
+                 ([0, 0, 9, 0], [0, 0, -1, 0], [0, 1, 0, 0], [1, 0, 0, 0]), ([1.5, 1.5, -7, 0], [0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0])]
+    env = Parser(texture_dirs=[ROOT], low_precision=low_precision).parse(text)
+    osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if low_precision else "")
+    env.camera.max_depth = 5
+    for loc, fwd, left, up in poses:
+        ocam = osc.camera()
+        for k in range(dim):
+            for cam in (env.camera, ocam):
+                cam.location[k] = loc[k]; cam.forward[k] = fwd[k]; cam.left[k] = left[k]; cam.up[k] = up[k]
+        for w, h in ((65, 65), (64, 48)):
+            img = env.render((w, h), want_hit_t=True)
+            orgb, ohit, ost = osc.render(w, h, max_depth=5, want_hit_t=True, camera=ocam)
+            assert np.array_equal(img.data, orgb), (loc, fwd, w, h, int((img.data != orgb).sum()))
+            assert img.stats == ost
+            both_nan = np.isnan(img.hit_t) & np.isnan(ohit)
+            gh = img.hit_t.astype(np.float32) if low_precision else img.hit_t
+            assert np.array_equal(gh[~both_nan], ohit[~both_nan])
+    env.close()
