@@ -123,6 +123,8 @@ SYMBOLS = {
     "eu_multi_destroy": (None, [C.c_void_p]),
     "eu_render_multi": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_void_p),
                                   C.POINTER(Stats)]),
+    "eu_render_multi_begin": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame)]),
+    "eu_render_multi_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Stats)]),
     "eu_multi_error": (C.c_char_p, [C.c_void_p]),
     "eu_trace_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

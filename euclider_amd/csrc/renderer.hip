@@ -887,17 +887,34 @@ __global__ void eu_restore_rows_kernel(const uint8_t *__restrict__ gathered, uin
     (void)row_begin;
 }
 
-struct eu_multi {
-    std::vector<eu_renderer *> r;            /* r[k] on devices[k]; r[0] is the root */
-    std::vector<int> devices;
-    std::vector<hipStream_t> stream;
-    std::vector<hipEvent_t> sent;
+/* One frame of eu_multi in flight: its per-device strip buffers, the root's gather / output buffers, a snapshot of every renderer's
+ * counters taken in stream order right behind its trace (the next frame's trace zeroes the live ones), and the frame itself (an
+ * overflowing device traces its strips again when the frame is collected).  Two slots: frame k's pack + peer transfer + row restore
+ * run on the devices' copy streams while frame k + 1 is traced (eu_render_multi_begin / _end). */
+struct MultiSlot {
     std::vector<uint32_t *> d_rgba;          /* per device: its strips, RGBA8 */
     std::vector<uint8_t *> d_rgb;            /* per device (k > 0): its strips packed to RGB8 */
     std::vector<size_t> cap_pixels;
+    std::vector<EuDevCounters *> d_cnt;      /* per device: counters of this frame's trace */
+    std::vector<hipEvent_t> traced, sent;    /* per device: strips traced + packed + counters saved / arrived at the root */
+    hipEvent_t restored = nullptr;           /* root: d_out holds the frame */
     uint8_t *d_gathered = nullptr;           /* root: n * max_rows * width * 3 */
     uint8_t *d_out = nullptr;                /* root: rows * width * 3, frame order */
     size_t gathered_bytes = 0, out_bytes = 0;
+    bool busy = false;
+    eu_camera cam; eu_frame f;
+    std::vector<eu_frame> fr;
+    std::vector<uint32_t> lrows;
+    size_t dev_stride = 0;
+};
+
+struct eu_multi {
+    std::vector<eu_renderer *> r;            /* r[k] on devices[k]; r[0] is the root */
+    std::vector<int> devices;
+    std::vector<hipStream_t> stream;         /* per device: trace + pack */
+    std::vector<hipStream_t> copy;           /* per device: peer transfer; the root's also restores the row order and reads back */
+    MultiSlot slot[2];
+    uint64_t begun = 0, ended = 0;
     std::string err;
 };
 
@@ -906,14 +923,22 @@ extern "C" void eu_multi_destroy(eu_multi *m) {
     for (size_t k = 0; k < m->r.size(); k++) {
         (void)hipSetDevice(m->devices[k]);
         if (k < m->stream.size() && m->stream[k]) { (void)hipStreamSynchronize(m->stream[k]); (void)hipStreamDestroy(m->stream[k]); }
-        if (k < m->sent.size() && m->sent[k]) (void)hipEventDestroy(m->sent[k]);
-        if (k < m->d_rgba.size() && m->d_rgba[k]) (void)hipFree(m->d_rgba[k]);
-        if (k < m->d_rgb.size() && m->d_rgb[k]) (void)hipFree(m->d_rgb[k]);
+        if (k < m->copy.size() && m->copy[k]) { (void)hipStreamSynchronize(m->copy[k]); (void)hipStreamDestroy(m->copy[k]); }
+        for (MultiSlot &s : m->slot) {
+            if (k < s.traced.size() && s.traced[k]) (void)hipEventDestroy(s.traced[k]);
+            if (k < s.sent.size() && s.sent[k]) (void)hipEventDestroy(s.sent[k]);
+            if (k < s.d_rgba.size() && s.d_rgba[k]) (void)hipFree(s.d_rgba[k]);
+            if (k < s.d_rgb.size() && s.d_rgb[k]) (void)hipFree(s.d_rgb[k]);
+            if (k < s.d_cnt.size() && s.d_cnt[k]) (void)hipFree(s.d_cnt[k]);
+        }
         if (m->r[k]) eu_renderer_destroy(m->r[k]);
     }
     if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
-    if (m->d_gathered) (void)hipFree(m->d_gathered);
-    if (m->d_out) (void)hipFree(m->d_out);
+    for (MultiSlot &s : m->slot) {
+        if (s.restored) (void)hipEventDestroy(s.restored);
+        if (s.d_gathered) (void)hipFree(s.d_gathered);
+        if (s.d_out) (void)hipFree(s.d_out);
+    }
     delete m;
 }
 
@@ -922,14 +947,23 @@ extern "C" int eu_multi_create_opts(const eu_scene *scene, const int *devices, i
     *out = nullptr;
     eu_multi *m = new eu_multi();
     m->devices.assign(devices, devices + n_devices);
-    m->r.assign(n_devices, nullptr); m->stream.assign(n_devices, nullptr); m->sent.assign(n_devices, nullptr);
-    m->d_rgba.assign(n_devices, nullptr); m->d_rgb.assign(n_devices, nullptr); m->cap_pixels.assign(n_devices, 0);
+    m->r.assign(n_devices, nullptr); m->stream.assign(n_devices, nullptr); m->copy.assign(n_devices, nullptr);
+    for (MultiSlot &s : m->slot) {
+        s.traced.assign(n_devices, nullptr); s.sent.assign(n_devices, nullptr); s.d_cnt.assign(n_devices, nullptr);
+        s.d_rgba.assign(n_devices, nullptr); s.d_rgb.assign(n_devices, nullptr); s.cap_pixels.assign(n_devices, 0);
+    }
     for (int k = 0; k < n_devices; k++) {
         int rc = eu_renderer_create_opts(scene, devices[k], opts, &m->r[k], err, errlen);
         if (rc != EU_OK) { eu_multi_destroy(m); return rc; }
         hipError_t e = hipSetDevice(devices[k]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream[k], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->sent[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->copy[k], hipStreamNonBlocking);
+        for (MultiSlot &s : m->slot) {
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.traced[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.sent[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipMalloc((void **)&s.d_cnt[k], sizeof(EuDevCounters));
+            if (e == hipSuccess && k == 0) e = hipEventCreateWithFlags(&s.restored, hipEventDisableTiming);
+        }
         if (e != hipSuccess) { set_err(err, errlen, std::string("eu_multi_create: ") + hipGetErrorString(e)); eu_multi_destroy(m); return EU_ERR_HIP; }
         if (k > 0 && devices[k] != devices[0]) {      /* direct xGMI transfers where the topology allows them (otherwise the runtime stages the copy) */
             int can = 0;
@@ -947,13 +981,16 @@ extern "C" int eu_multi_create(const eu_scene *scene, const int *devices, int n_
     return eu_multi_create_opts(scene, devices, n_devices, nullptr, out, err, errlen);
 }
 
-/* before an error return: nothing of this frame may still be in flight on any device when the caller sees the failure */
+/* before an error return: nothing may still be in flight on any device when the caller sees the failure (frames begun are lost) */
 static void multi_drain(eu_multi *m) {
     for (size_t k = 0; k < m->r.size(); k++) {
         if (hipSetDevice(m->devices[k]) != hipSuccess) continue;
         if (m->stream[k]) (void)hipStreamSynchronize(m->stream[k]);
+        if (m->copy[k]) (void)hipStreamSynchronize(m->copy[k]);
     }
     (void)hipGetLastError();
+    for (MultiSlot &s : m->slot) s.busy = false;
+    m->ended = m->begun;
 }
 
 #define MULTI_TRY(expr)                                                                   \
@@ -966,116 +1003,168 @@ static void multi_drain(eu_multi *m) {
         }                                                                                 \
     } while (0)
 
-extern "C" int eu_render_multi(eu_multi *m, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats) {
+/* device k's strips of slot s: counters saved and strips packed behind the trace on its trace stream, then -- on its copy stream, so
+ * that the trace stream is free for the next frame -- one transfer into its slot of the root's buffer */
+static int multi_pack_and_send(eu_multi *m, MultiSlot &s, uint32_t k) {
+    const uint32_t W = s.f.width;
+    const size_t row_bytes = (size_t)W * 3;
+    MULTI_TRY(hipSetDevice(m->devices[k]));
+    MULTI_TRY(hipMemcpyAsync(s.d_cnt[k], m->r[k]->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToDevice, m->stream[k]));
+    uint8_t *packed = k == 0 ? s.d_gathered : s.d_rgb[k];      /* the root packs straight into slot 0 */
+    int rc = eu_pack_rgb_device(m->r[k], s.d_rgba[k], packed, (size_t)s.lrows[k] * W, m->stream[k]);
+    if (rc != EU_OK) { m->err = m->r[k]->err; multi_drain(m); return rc; }
+    MULTI_TRY(hipEventRecord(s.traced[k], m->stream[k]));
+    MULTI_TRY(hipStreamWaitEvent(m->copy[k], s.traced[k], 0));
+    if (k > 0) MULTI_TRY(hipMemcpyPeerAsync(s.d_gathered + (size_t)k * s.dev_stride, m->devices[0], packed, m->devices[k], (size_t)s.lrows[k] * row_bytes, m->copy[k]));
+    MULTI_TRY(hipEventRecord(s.sent[k], m->copy[k]));
+    return EU_OK;
+}
+
+static int multi_restore(eu_multi *m, MultiSlot &s) {
+    const uint32_t n = (uint32_t)m->r.size(), rows = s.f.row_end - s.f.row_begin, W = s.f.width;
+    const size_t row_bytes = (size_t)W * 3;
+    MULTI_TRY(hipSetDevice(m->devices[0]));
+    for (uint32_t k = 0; k < n; k++) if (s.lrows[k]) MULTI_TRY(hipStreamWaitEvent(m->copy[0], s.sent[k], 0));
+    if (n > 1) {
+        unsigned gx = (unsigned)((row_bytes + 255) / 256); if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(eu_restore_rows_kernel, dim3(gx, rows), dim3(256), 0, m->copy[0], s.d_gathered, s.d_out, W, s.f.row_begin, rows, n, s.dev_stride);
+        MULTI_TRY(hipGetLastError());
+    }
+    MULTI_TRY(hipEventRecord(s.restored, m->copy[0]));
+    return EU_OK;
+}
+
+extern "C" int eu_render_multi_begin(eu_multi *m, const eu_camera *cam, const eu_frame *f) {
     if (!m || !cam || !f) return EU_ERR_INVALID_ARGUMENT;
     if (f->width == 0 || f->height == 0 || f->row_begin > f->row_end || f->row_end > f->height || f->strip_count > 1) return EU_ERR_INVALID_ARGUMENT;
+    if (m->begun - m->ended >= 2) { m->err = "eu_render_multi_begin: two frames are in flight already (collect one with eu_render_multi_end)"; return EU_ERR_INVALID_ARGUMENT; }
+    MultiSlot &s = m->slot[m->begun % 2];
     const uint32_t n = (uint32_t)m->r.size(), rows = f->row_end - f->row_begin, W = f->width;
-    if (stats) memset(stats, 0, sizeof *stats);
+    s.cam = *cam; s.f = *f;
+    s.fr.assign(n, *f); s.lrows.assign(n, 0);
+    s.busy = true;
+    m->begun++;
     if (rows == 0) return EU_OK;
     const size_t row_bytes = (size_t)W * 3;
     uint32_t max_rows = 0;
-    std::vector<eu_frame> fr(n, *f);
-    std::vector<uint32_t> lrows(n, 0);
     for (uint32_t k = 0; k < n; k++) {
-        fr[k].strip_count = n; fr[k].strip_index = k;
-        lrows[k] = n > 1 ? eu_frame_local_rows(&fr[k]) : rows;
-        if (n == 1) { fr[k].strip_count = 0; fr[k].strip_index = 0; }
-        if (lrows[k] > max_rows) max_rows = lrows[k];
+        s.fr[k].strip_count = n; s.fr[k].strip_index = k;
+        s.lrows[k] = n > 1 ? eu_frame_local_rows(&s.fr[k]) : rows;
+        if (n == 1) { s.fr[k].strip_count = 0; s.fr[k].strip_index = 0; }
+        if (s.lrows[k] > max_rows) max_rows = s.lrows[k];
     }
-    const size_t dev_stride = (size_t)max_rows * row_bytes;
+    s.dev_stride = (size_t)max_rows * row_bytes;
     /* buffers, grown on demand */
     MULTI_TRY(hipSetDevice(m->devices[0]));
-    if (m->gathered_bytes < dev_stride * n + 16) {
-        if (m->d_gathered) (void)hipFree(m->d_gathered);
-        m->d_gathered = nullptr; m->gathered_bytes = 0;
-        MULTI_TRY(hipMalloc((void **)&m->d_gathered, dev_stride * n + 16));
-        m->gathered_bytes = dev_stride * n + 16;
+    if (s.gathered_bytes < s.dev_stride * n + 16) {
+        if (s.d_gathered) (void)hipFree(s.d_gathered);
+        s.d_gathered = nullptr; s.gathered_bytes = 0;
+        MULTI_TRY(hipMalloc((void **)&s.d_gathered, s.dev_stride * n + 16));
+        s.gathered_bytes = s.dev_stride * n + 16;
     }
-    if (m->out_bytes < (size_t)rows * row_bytes + 16) {
-        if (m->d_out) (void)hipFree(m->d_out);
-        m->d_out = nullptr; m->out_bytes = 0;
-        MULTI_TRY(hipMalloc((void **)&m->d_out, (size_t)rows * row_bytes + 16));
-        m->out_bytes = (size_t)rows * row_bytes + 16;
+    if (s.out_bytes < (size_t)rows * row_bytes + 16) {
+        if (s.d_out) (void)hipFree(s.d_out);
+        s.d_out = nullptr; s.out_bytes = 0;
+        MULTI_TRY(hipMalloc((void **)&s.d_out, (size_t)rows * row_bytes + 16));
+        s.out_bytes = (size_t)rows * row_bytes + 16;
     }
     for (uint32_t k = 0; k < n; k++) {
         const size_t pixels = (size_t)max_rows * W;
-        if (m->cap_pixels[k] < pixels) {
+        if (s.cap_pixels[k] < pixels) {
             MULTI_TRY(hipSetDevice(m->devices[k]));
-            if (m->d_rgba[k]) (void)hipFree(m->d_rgba[k]);
-            if (m->d_rgb[k]) (void)hipFree(m->d_rgb[k]);
-            m->d_rgba[k] = nullptr; m->d_rgb[k] = nullptr; m->cap_pixels[k] = 0;
-            MULTI_TRY(hipMalloc((void **)&m->d_rgba[k], pixels * 4));
-            if (k > 0) MULTI_TRY(hipMalloc((void **)&m->d_rgb[k], pixels * 3 + 16));
-            m->cap_pixels[k] = pixels;
+            if (s.d_rgba[k]) (void)hipFree(s.d_rgba[k]);
+            if (s.d_rgb[k]) (void)hipFree(s.d_rgb[k]);
+            s.d_rgba[k] = nullptr; s.d_rgb[k] = nullptr; s.cap_pixels[k] = 0;
+            MULTI_TRY(hipMalloc((void **)&s.d_rgba[k], pixels * 4));
+            if (k > 0) MULTI_TRY(hipMalloc((void **)&s.d_rgb[k], pixels * 3 + 16));
+            s.cap_pixels[k] = pixels;
         }
     }
     /* every renderer's work buffers, streams and events first: no allocation (which may synchronise or clear memory) happens
      * once the first device's kernels are in flight */
     for (uint32_t k = 0; k < n; k++) {
-        if (lrows[k] == 0) continue;
+        if (s.lrows[k] == 0) continue;
         MULTI_TRY(hipSetDevice(m->devices[k]));
         m->r[k]->prepare_only = true;
-        const int prc = render_device_impl(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, nullptr);
+        const int prc = render_device_impl(m->r[k], cam, &s.fr[k], m->stream[k], s.d_rgba[k], nullptr, nullptr);
         m->r[k]->prepare_only = false;
         if (prc != EU_OK) { m->err = m->r[k]->err; multi_drain(m); return prc; }
     }
     /* trace everywhere ... */
     for (uint32_t k = 0; k < n; k++) {
-        if (lrows[k] == 0) continue;
+        if (s.lrows[k] == 0) continue;
         MULTI_TRY(hipSetDevice(m->devices[k]));
-        int rc = render_device_impl(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, nullptr);
+        int rc = render_device_impl(m->r[k], cam, &s.fr[k], m->stream[k], s.d_rgba[k], nullptr, nullptr);
         if (rc != EU_OK) { m->err = m->r[k]->err; multi_drain(m); return rc; }
     }
-    /* ... then pack, and one transfer per device into its slot of the root's buffer */
-    auto pack_and_send = [&](uint32_t k) -> int {
-        MULTI_TRY(hipSetDevice(m->devices[k]));
-        uint8_t *packed = k == 0 ? m->d_gathered : m->d_rgb[k];      /* the root packs straight into slot 0 */
-        int rc = eu_pack_rgb_device(m->r[k], m->d_rgba[k], packed, (size_t)lrows[k] * W, m->stream[k]);
-        if (rc != EU_OK) { m->err = m->r[k]->err; multi_drain(m); return rc; }
-        if (k > 0) MULTI_TRY(hipMemcpyPeerAsync(m->d_gathered + (size_t)k * dev_stride, m->devices[0], packed, m->devices[k], (size_t)lrows[k] * row_bytes, m->stream[k]));
-        MULTI_TRY(hipEventRecord(m->sent[k], m->stream[k]));
-        return EU_OK;
-    };
-    auto restore = [&]() -> int {
-        MULTI_TRY(hipSetDevice(m->devices[0]));
-        for (uint32_t k = 1; k < n; k++) if (lrows[k]) MULTI_TRY(hipStreamWaitEvent(m->stream[0], m->sent[k], 0));
-        if (n > 1) {
-            unsigned gx = (unsigned)((row_bytes + 255) / 256); if (gx > 64) gx = 64;
-            hipLaunchKernelGGL(eu_restore_rows_kernel, dim3(gx, rows), dim3(256), 0, m->stream[0], m->d_gathered, m->d_out, W, f->row_begin, rows, n, dev_stride);
-            MULTI_TRY(hipGetLastError());
-        }
-        return EU_OK;
-    };
-    for (uint32_t k = 0; k < n; k++) if (lrows[k]) { const int rc = pack_and_send(k); if (rc != EU_OK) return rc; }
-    int rc = restore();
-    if (rc != EU_OK) return rc;
+    /* ... then pack, one transfer per device into its slot of the root's buffer, and the row order restored there */
+    for (uint32_t k = 0; k < n; k++) if (s.lrows[k]) { const int rc = multi_pack_and_send(m, s, k); if (rc != EU_OK) return rc; }
+    return multi_restore(m, s);
+}
+
+extern "C" int eu_render_multi_end(eu_multi *m, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats) {
+    if (!m) return EU_ERR_INVALID_ARGUMENT;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (m->begun == m->ended) { m->err = "eu_render_multi_end: no frame in flight"; return EU_ERR_INVALID_ARGUMENT; }
+    MultiSlot &s = m->slot[m->ended % 2];
+    const uint32_t n = (uint32_t)m->r.size(), rows = s.f.row_end - s.f.row_begin, W = s.f.width;
+    const size_t row_bytes = (size_t)W * 3;
+    if (rows == 0) { s.busy = false; m->ended++; if (rgb_dev_root) *rgb_dev_root = nullptr; return EU_OK; }
     /* a device whose ray queues overflowed (the glass-heavy strips are exactly the fan-out case) traces its strips again with the
-     * stack-based kernel, as eu_render does; its strips are packed and sent again and the row order restored once more */
+     * stack-based kernel, as eu_render does -- behind whatever its trace stream holds of the next frame; its strips are packed and
+     * sent again and the row order restored once more */
+    std::vector<EuDevCounters> c(n);
+    auto counters_of = [&](uint32_t k) -> int {
+        MULTI_TRY(hipSetDevice(m->devices[k]));
+        MULTI_TRY(hipEventSynchronize(s.traced[k]));
+        MULTI_TRY(hipMemcpy(&c[k], s.d_cnt[k], sizeof(EuDevCounters), hipMemcpyDeviceToHost));
+        return EU_OK;
+    };
     bool any_retraced = false;
     for (uint32_t k = 0; k < n; k++) {
-        if (lrows[k] == 0) continue;
-        bool retraced = false;
-        rc = retrace_if_overflowed(m->r[k], cam, &fr[k], m->stream[k], m->d_rgba[k], nullptr, &retraced);
-        if (rc != EU_OK) { m->err = m->r[k]->err; multi_drain(m); return rc; }
-        if (retraced) { any_retraced = true; rc = pack_and_send(k); if (rc != EU_OK) return rc; }
+        if (s.lrows[k] == 0) continue;
+        int rc = counters_of(k);
+        if (rc != EU_OK) return rc;
+        if (!c[k].overflow || !m->r[k]->use_wavefront) continue;
+        eu_renderer *r = m->r[k];
+        r->use_wavefront = false;
+        r->retraces++;
+        rc = render_device_impl(r, &s.cam, &s.fr[k], m->stream[k], s.d_rgba[k], nullptr, nullptr);
+        r->use_wavefront = true;
+        if (rc != EU_OK) { m->err = r->err; multi_drain(m); return rc; }
+        any_retraced = true;
+        if ((rc = multi_pack_and_send(m, s, k)) != EU_OK) return rc;
+        if ((rc = counters_of(k)) != EU_OK) return rc;
     }
-    if (any_retraced) { rc = restore(); if (rc != EU_OK) return rc; }
+    if (any_retraced) { const int rc = multi_restore(m, s); if (rc != EU_OK) return rc; }
     MULTI_TRY(hipSetDevice(m->devices[0]));
-    uint8_t *result = n > 1 ? m->d_out : m->d_gathered;
-    if (rgb_host) MULTI_TRY(hipMemcpyAsync(rgb_host, result, (size_t)rows * row_bytes, hipMemcpyDeviceToHost, m->stream[0]));
-    MULTI_TRY(hipStreamSynchronize(m->stream[0]));
-    if (rgb_dev_root) *rgb_dev_root = result;
+    uint8_t *result = n > 1 ? s.d_out : s.d_gathered;
+    MULTI_TRY(hipEventSynchronize(s.restored));
+    if (rgb_host) {
+        MULTI_TRY(hipMemcpyAsync(rgb_host, result, (size_t)rows * row_bytes, hipMemcpyDeviceToHost, m->copy[0]));
+        MULTI_TRY(hipStreamSynchronize(m->copy[0]));
+    }
+    if (rgb_dev_root) *rgb_dev_root = result;      /* valid until the second eu_render_multi_begin from here */
+    s.busy = false;
+    m->ended++;
     int worst = EU_OK;
     eu_stats sum = {0, 0, 0, 0};
     for (uint32_t k = 0; k < n; k++) {
-        if (lrows[k] == 0) continue;
-        eu_stats st;
-        const int src = eu_renderer_stats(m->r[k], &st);
-        if (src != EU_OK) { m->err = m->r[k]->err; worst = src; continue; }
-        sum.rays += st.rays; sum.bg_samples += st.bg_samples; sum.nan_pixels += st.nan_pixels; sum.errors += st.errors;
+        if (s.lrows[k] == 0) continue;
+        if (c[k].overflow) { m->err = "ray queue overflow on device " + std::to_string(m->devices[k]) + " that the stack kernel did not take over"; worst = EU_ERR_CAPACITY; continue; }
+        sum.rays += c[k].rays; sum.bg_samples += c[k].bg_samples; sum.nan_pixels += c[k].nan_pixels; sum.errors += c[k].errors;
     }
     if (stats && worst == EU_OK) *stats = sum;      /* (never partially summed) */
     return worst;
+}
+
+extern "C" int eu_render_multi(eu_multi *m, const eu_camera *cam, const eu_frame *f, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats) {
+    if (!m || !cam || !f) return EU_ERR_INVALID_ARGUMENT;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (m->begun != m->ended) { m->err = "eu_render_multi: frames begun with eu_render_multi_begin are still in flight"; return EU_ERR_INVALID_ARGUMENT; }
+    const int rc = eu_render_multi_begin(m, cam, f);
+    if (rc != EU_OK) return rc;
+    return eu_render_multi_end(m, rgb_host, rgb_dev_root, stats);
 }
 
 extern "C" const char *eu_multi_error(const eu_multi *m) { return m ? m->err.c_str() : ""; }

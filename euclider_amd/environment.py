@@ -231,13 +231,7 @@ class Environment:
         img.hit_t = hit
         return img
 
-    def render_multi(self, dimensions, devices, time=0.0, context=None, rows=None):
-        """Environment::render with the frame's 8-row strips dealt round-robin over `devices` (eu_render_multi: one
-        process, one renderer per listed device, packed strips gathered on devices[0], row order restored there)."""
-        context = context or SimulationContext()
-        width, height = dimensions
-        bw, bh = width // context.resolution, height // context.resolution
-        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, None)
+    def _multi(self, devices):
         key = tuple(int(d) for d in devices)
         L = self._L
         if not hasattr(self, "_multis"):
@@ -251,12 +245,52 @@ class Environment:
             if rc != _capi.EU_OK:
                 raise EuError(rc, err.value.decode())
             self._multis[key] = out
+            self._multi_pending = getattr(self, "_multi_pending", {})
+            self._multi_pending[key] = []
+        return key, self._multis[key]
+
+    def render_multi_begin(self, dimensions, devices, time=0.0, context=None, rows=None):
+        """eu_render_multi_begin: queue the frame on all devices and return; at most two frames in flight per device list."""
+        context = context or SimulationContext()
+        width, height = dimensions
+        bw, bh = width // context.resolution, height // context.resolution
+        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, None)
+        key, m = self._multi(devices)
+        rc = self._L.eu_render_multi_begin(m, C.byref(self.camera), C.byref(fr))
+        if rc != _capi.EU_OK:
+            raise EuError(rc, self._L.eu_multi_error(m).decode())
+        self._multi_pending[key].append((bw, fr.row_end - fr.row_begin))
+
+    def render_multi_end(self, devices):
+        """eu_render_multi_end: the oldest frame begun on this device list."""
+        key, m = self._multi(devices)
+        if not self._multi_pending[key]:
+            raise EuError(_capi.EU_ERR_INVALID_ARGUMENT, "no frame in flight")
+        bw, nrows = self._multi_pending[key].pop(0)
+        rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
+        st = _capi.Stats()
+        rc = self._L.eu_render_multi_end(m, rgb.ctypes.data, None, C.byref(st))
+        if rc != _capi.EU_OK:
+            raise EuError(rc, self._L.eu_multi_error(m).decode())
+        img = RawImage2d(rgb, bw, nrows)
+        img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
+        return img
+
+    def render_multi(self, dimensions, devices, time=0.0, context=None, rows=None):
+        """Environment::render with the frame's 8-row strips dealt round-robin over `devices` (eu_render_multi: one
+        process, one renderer per listed device, packed strips gathered on devices[0], row order restored there)."""
+        context = context or SimulationContext()
+        width, height = dimensions
+        bw, bh = width // context.resolution, height // context.resolution
+        fr = self._frame(bw, bh, _duration_to_ms(time), context.debugging, rows, None)
+        key, m = self._multi(devices)
+        L = self._L
         nrows = fr.row_end - fr.row_begin
         rgb = np.zeros((nrows, bw, 3), dtype=np.uint8)
         st = _capi.Stats()
-        rc = L.eu_render_multi(self._multis[key], C.byref(self.camera), C.byref(fr), rgb.ctypes.data, None, C.byref(st))
+        rc = L.eu_render_multi(m, C.byref(self.camera), C.byref(fr), rgb.ctypes.data, None, C.byref(st))
         if rc != _capi.EU_OK:
-            raise EuError(rc, L.eu_multi_error(self._multis[key]).decode())
+            raise EuError(rc, L.eu_multi_error(m).decode())
         img = RawImage2d(rgb, bw, nrows)
         img.stats = {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
         return img

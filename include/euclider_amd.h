@@ -230,6 +230,14 @@ int eu_multi_create(const eu_scene *, const int *devices, int n_devices, eu_mult
 int eu_multi_create_opts(const eu_scene *, const int *devices, int n_devices, const eu_renderer_opts *opts, eu_multi **out, char *err, size_t errlen);
 void eu_multi_destroy(eu_multi *);
 int eu_render_multi(eu_multi *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats);
+/* The same in two halves, for a frame loop (simulation.rs:93-150): eu_render_multi_begin queues the frame on all devices and
+ * returns; eu_render_multi_end waits for the OLDEST frame begun, retraces overflowed strips, and hands out image and stats as
+ * above.  Two frames may be in flight (a third begin is EU_ERR_INVALID_ARGUMENT): the strip buffers, the root's gather and
+ * output buffers and the per-device counters exist twice, and the pack + peer transfer + row restore of frame k run on
+ * separate copy streams while frame k + 1 is traced.  rgb_dev_root stays valid until the second begin after its end.
+ * eu_render_multi == begin + end, and refuses while frames begun this way are in flight. */
+int eu_render_multi_begin(eu_multi *, const eu_camera *, const eu_frame *);
+int eu_render_multi_end(eu_multi *, uint8_t *rgb_host, void **rgb_dev_root, eu_stats *stats);
 const char *eu_multi_error(const eu_multi *);
 
 /* ---- camera motion ("next" row f3 of the scope table) ------------------------------------------------

@@ -343,3 +343,52 @@ def test_render_multi_on_one_device(ranks, W, H, rows):
     if ranks == 2 and rows is None:
         orgb, _, ost = load_scene_file(path).render(W, H, max_depth=6)
         assert np.array_equal(multi.data, orgb) and multi.stats["rays"] == ost["rays"]
+
+
+@pytest.mark.parametrize("ray_factor", [None, 0.05])
+def test_render_multi_two_frames_in_flight(ray_factor):
+    """eu_render_multi_begin / _end with three renderers on the one device: frame k's pack, transfer and row restore run on the copy
+    streams while frame k + 1 is traced (both sets of buffers in use at once), frames with different cameras, times and row windows
+    come back in order and equal the single-renderer frames -- also when every frame overflows its ray queues and is traced again by
+    the stack kernel at collection time, behind the next frame's work (ray_factor 0.05)."""
+    from euclider_amd import Parser, _capi
+    from euclider_amd.environment import EuError
+    path = os.path.join(SCENES, "3d_room.json")
+    ref = Parser().parse_file(path)
+    ref.camera.max_depth = 4
+    env = Parser().parse_file(path)
+    if ray_factor is not None:
+        env.configure(kernel="wavefront", ray_factor=ray_factor, streams=1)
+    env.camera.max_depth = 4
+    frames = [((320, 180), 0.0, None, 0.0), ((320, 180), 0.5, None, 0.4), ((256, 144), 1.0, (8, 120), -0.3), ((320, 180), 1.5, None, 0.0), ((64, 64), 2.0, None, 0.1)]
+    if ray_factor is not None:
+        frames = [((1920, 1080), t, r, dx) for (_, t, r, dx) in frames[:3]]
+    devs = [0, 0, 0]
+
+    def pose(e, dx):
+        e.camera.location[1] = dx
+
+    want = []
+    for dims, t, rows, dx in frames:
+        pose(ref, dx)
+        want.append(ref.render(dims, time=t, rows=rows))
+    ref.close()
+    got = []
+    pose(env, frames[0][3]); env.render_multi_begin(frames[0][0], devs, time=frames[0][1], rows=frames[0][2])
+    for dims, t, rows, dx in frames[1:]:
+        pose(env, dx); env.render_multi_begin(dims, devs, time=t, rows=rows)      # two in flight
+        if len(got) == 0:
+            with pytest.raises(EuError) as ei:                                   # a third is refused, and so is the one-call form
+                env.render_multi_begin(dims, devs)
+            assert ei.value.code == _capi.EU_ERR_INVALID_ARGUMENT
+            with pytest.raises(EuError):
+                env.render_multi(dims, devs)
+        got.append(env.render_multi_end(devs))
+    got.append(env.render_multi_end(devs))
+    with pytest.raises(EuError):
+        env.render_multi_end(devs)
+    for w, g in zip(want, got):
+        assert g.data.shape == w.data.shape and np.array_equal(g.data, w.data) and g.stats == w.stats
+    pose(env, frames[0][3])
+    assert np.array_equal(env.render_multi(frames[0][0], devs, time=frames[0][1], rows=frames[0][2]).data, want[0].data)      # the one-call form still works afterwards
+    env.close()

@@ -1,5 +1,8 @@
-"""Diagnostic: where eval_shape spends a wave's time (needs a -DEU_PROFILE_SHAPE build, e.g. EU_LIB_PATH=variants/shape_prof.so).
-Usage: python tools/shape_profile.py [scene] [depth] [w] [h]"""
+"""Diagnostic: where eval_shape (or, EU_PROFILE_KERNEL=shade, the shade kernel) spends a wave's time.  The interpreter kernels need a
+-DEU_PROFILE_SHAPE / -DEU_PROFILE_SHADE_WAVE build of the library (tools/build_variant.sh, EU_LIB_PATH=...); with EU_PROFILE_JIT=1 the
+scene-specialised kernels are compiled with that flag instead (any build of the library).  The stamps cost time themselves: read the
+shares as a ranking, not as a budget.
+Usage: [EU_PROFILE_JIT=1] [EU_PROFILE_KERNEL=shade] python tools/shape_profile.py [scene] [depth] [w] [h]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +16,8 @@ depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 h = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
+if os.environ.get("EU_PROFILE_JIT"):
+    env.configure(specialize="sync", jit_flags="-DEU_PROFILE_SHADE_WAVE" if os.environ.get("EU_PROFILE_KERNEL") == "shade" else "-DEU_PROFILE_SHAPE")
 env.camera.max_depth = depth
 img = env.render((w, h))
 ph = (C.c_uint64 * 16)()
