@@ -25,9 +25,15 @@ def main(paths=None, workers=None):
     paths = paths or sorted(glob.glob(os.path.join(ROOT, "scenes", "*.json")))
     os.makedirs(CACHE, exist_ok=True)
     jobs = [(p, low) for p in paths for low in (False, True)]
+    keep = set()
     with ProcessPoolExecutor(max_workers=workers or min(8, os.cpu_count() or 1)) as ex:
         for name, low, info, dt in ex.map(one, jobs):
+            keep.add(info["key"])
             print("%-22s %s  %s  %6.1f s%s" % (name, "f32" if low else "f64", info["key"], dt, "  (cached)" if info["from_cache"] else ""))
+    if len(paths) >= 10:      # a full run: code objects of earlier builds of the device headers are of no use any more
+        for f in os.listdir(CACHE):
+            if f.endswith(".hsaco") and f[:-6].split("_")[0] not in keep and f[:-6] not in keep:
+                os.remove(os.path.join(CACHE, f))
 
 
 if __name__ == "__main__":
