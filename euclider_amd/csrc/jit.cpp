@@ -532,13 +532,15 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
      * else a private array of exactly the entries this scene needs (the ahead-of-time kernels only have 16 and 96) */
     const uint32_t soft_cap = h.hit_cap & 0xffffu;      /* (bits 16..: the strict bound of the stack kernels, flat_scene.h) */
     const uint32_t cap = soft_cap < 8 ? 8u : ((soft_cap + 3u) & ~3u);
-    plan.hs_lds = soft_cap <= 32;
+    plan.hs_lds = cap <= 24;      /* two workgroups per CU at least: 24 entries x 64 lanes x (sizeof(real) + 4) B x 4 waves = 72 KB */
     plan.hs_cap = cap;
+    for (auto &f : plan.extra_flags)      /* tuning experiments (bench.py --jit-flags=-DEU_HS_CAP=16): a smaller stack than the static bound; a lane that needs more marks the frame (EU_CNT_HS_FULL) */
+        if (f.rfind("-DEU_HS_CAP=", 0) == 0) { const unsigned v = (unsigned)atoi(f.c_str() + 12); if (v >= 4 && v <= 96) { plan.hs_cap = v; plan.hs_lds = v <= 24; } }
     plan.too_large = h.n_ops > kJitMaxShapeOps || h.n_entities > kJitMaxEntities;
     Gen g(flat);
     g.generate();
     Out tail;
-    const unsigned hscap = plan.hs_lds ? 0u : cap;
+    const unsigned hscap = plan.hs_lds ? 0u : plan.hs_cap;
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen,\n"
            "        EuWfBuffers B, EuDevCounters *counters) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
            "    wf_intersect_body<%d, %u, EuJit, false>(scene_g, hs_cap, gen, cam, fr, B, counters, nullptr, lds_dyn);\n}\n\n", plan.dim, hscap);

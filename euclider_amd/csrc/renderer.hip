@@ -449,7 +449,8 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     if (r->prepare_only) return EU_OK;      /* buffers, streams and events exist now: nothing is allocated while the frame is in flight */
     const bool jit = r->jit_intersect != nullptr;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
-    const bool hs_lds = jit ? r->jit_hs_lds : r->hit_cap <= 32;      /* else: private (scratch) hit stack */
+    if (jit && r->jit_hs_cap) hs_cap = r->jit_hs_cap;      /* (the same unless the plan was tuned: jit.cpp) */
+    const bool hs_lds = jit ? r->jit_hs_lds : hs_cap <= 24;      /* two workgroups per CU at least; else: private (scratch) hit stack */
     const bool hs_small = !hs_lds && r->hit_cap <= 16;
     const size_t isect_lds = hs_lds ? (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * (sizeof(real) + 4) : 0;     /* (t, code) per entry; the intersect kernel reads the scene through scalar loads */
     /* the interpreter's shade kernel: dynamic LDS = the colour-operand stack (color_depth RGBA reals per lane) and, when three

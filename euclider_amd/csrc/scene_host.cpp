@@ -846,8 +846,13 @@ struct Flattener {
              * consumed.  At an entity's root only element 0 is ever looked at, so the extra slot is not reserved there. */
             const uint32_t extra = s.operation == SetOperation::Complement ? 1u : 0u;
             len = HitUse{la.soft + lb.soft + extra, la.strict + lb.strict + extra};
-            note(HitUse{base_use.soft + 2 * (la.soft + lb.soft) + (is_root ? 0u : extra),       /* inputs + merge output */
-                        base_use.strict + 2 * (la.strict + lb.strict) + (is_root ? 0u : extra)});
+            /* inputs + merge output (csg_merge).  At an entity's root the merge stops at its first element: one slot.  A right operand
+             * of at most two hits is read into registers and the output is written over it. */
+            auto merge_use = [&](uint32_t a, uint32_t b) {
+                const uint32_t out = is_root ? 1u : a + b + extra;
+                return a + (b <= 2u ? std::max(b, out) : b + out);
+            };
+            note(HitUse{base_use.soft + merge_use(la.soft, lb.soft), base_use.strict + merge_use(la.strict, lb.strict)});
             if (depth + 2 > list_depth) list_depth = depth + 2;
             op.kind = (uint8_t)(EU_SH_UNION + (int)s.operation);
             op.param = 0;

@@ -869,7 +869,14 @@ EU_DEV CsgList csg_merge(uint32_t kind, bool is_root, HS &hs, uint32_t &sp, cons
     const bool unk_a = A.unk, unk_b = B.unk;
     bool out_unk = false;
     const bool rep_a = A.rep && na > 0, rep_b = B.rep && nb > 0;
-    const uint32_t b0 = sp - nb, a0 = b0 - na, o0 = sp;
+    const uint32_t b0 = sp - nb, a0 = b0 - na;
+    /* A right operand of at most two hits (a leaf, a box: every B of a left fold) is taken into registers and the output is written
+     * over it -- the loader's bound counts on that (scene_host.cpp: emit_shape); a longer B stays where it is, output above it. */
+    const bool b_regs = nb <= 2u;
+    real rb_t0 = R(0.0), rb_t1 = R(0.0); uint32_t rb_c0 = 0, rb_c1 = 0;
+    if (b_regs && nb >= 1u) { rb_t0 = hs.gt(b0); rb_c0 = hs.gc(b0); }
+    if (b_regs && nb == 2u) { rb_t1 = hs.gt(b0 + 1); rb_c1 = hs.gc(b0 + 1); }
+    const uint32_t o0 = b_regs ? b0 : sp;
     uint32_t ia = 0, ib = 0, no = 0;
     bool out_rep = false;
     const uint32_t guard_max = 4 * (na + nb) + 8;
@@ -880,7 +887,11 @@ EU_DEV CsgList csg_merge(uint32_t kind, bool is_root, HS &hs, uint32_t &sp, cons
         if (guard >= guard_max) { out_unk = true; break; }                    /* runaway: the reference would spin here */
         real ta = R(0.0), tb = R(0.0); uint32_t ca = 0, cb = 0;
         if (sa) { uint32_t k = a0 + (ia < na ? ia : na - 1); ta = hs.gt(k); ca = hs.gc(k); }
-        if (sb) { uint32_t k = b0 + (ib < nb ? ib : nb - 1); tb = hs.gt(k); cb = hs.gc(k); }
+        if (sb) {
+            const uint32_t kb = ib < nb ? ib : nb - 1;
+            if (b_regs) { tb = kb == 0u ? rb_t0 : rb_t1; cb = kb == 0u ? rb_c0 : rb_c1; }
+            else { tb = hs.gt(b0 + kb); cb = hs.gc(b0 + kb); }
+        }
         const bool both = sa && sb;
         const bool take_a = both ? (ta < tb) : sa;       /* ties go to b (shape.rs:226,304,375,448) */
         if (kind == EU_SH_COMPLEMENT && !both && sa) {   /* shape.rs:390-392: returns a without advancing */
