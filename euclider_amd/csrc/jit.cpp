@@ -535,7 +535,8 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
     plan.hs_lds = cap <= 24;      /* two workgroups per CU at least: 24 entries x 64 lanes x (sizeof(real) + 4) B x 4 waves = 72 KB */
     plan.hs_cap = cap;
     for (auto &f : plan.extra_flags)      /* tuning experiments (bench.py --jit-flags=-DEU_HS_CAP=16): a smaller stack than the static bound; a lane that needs more marks the frame (EU_CNT_HS_FULL) */
-        if (f.rfind("-DEU_HS_CAP=", 0) == 0) { const unsigned v = (unsigned)atoi(f.c_str() + 12); if (v >= 4 && v <= 96) { plan.hs_cap = v; plan.hs_lds = v <= 24; } }
+        if (f == "-DEU_HS_PRIVATE") plan.hs_lds = false;
+        else if (f.rfind("-DEU_HS_CAP=", 0) == 0) { const unsigned v = (unsigned)atoi(f.c_str() + 12); if (v >= 4 && v <= 96) { plan.hs_cap = v; plan.hs_lds = v <= 24; } }
     plan.too_large = h.n_ops > kJitMaxShapeOps || h.n_entities > kJitMaxEntities;
     Gen g(flat);
     g.generate();
