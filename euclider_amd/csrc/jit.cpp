@@ -359,6 +359,12 @@ struct Gen {
     void generate() {
         const uint32_t ne = h->n_entities;
         o.f("/* generated by euclider_amd (%s): trace kernels specialised for one scene: %u entities, %u shape ops, dim %d */\n", EU_JIT_VERSION, ne, h->n_ops, D);
+        /* tuning of the specialised shade kernel (measured with `--jit-flags`, one call per sweep): windows of 2048 rays sorted together
+         * where there are surfaces to sort by (three or more; the kernel halves and quarters its windows by itself when a launch is
+         * small; 4d_frame, one surface, loses 1 % with the larger window) and launch bounds of two waves per SIMD -- the
+         * kernel still runs three (129 VGPRs), the compiler is only freed from the 168-register limit: 3d_room 7.4 -> 7.7 Gray/s,
+         * 3d_hallways / 4d_frame / 4d_cylinders within +-1 %.  The ahead-of-time interpreter kernels keep 1024 / 3. */
+        o.f("#ifndef EU_WF_WIN\n#define EU_WF_WIN %u\n#endif\n#ifndef EU_SHADE_WAVES\n#define EU_SHADE_WAVES 2\n#endif\n", h->n_surfaces >= 3 ? 2048u : 1024u);
         o.f("#include \"trace_wavefront.h\"\n\n");
         o.f("template <int D> EU_DEV bool point_outside_bound(const real *Bd, const real *p) {\n    real rr = R(0.0);\n#pragma unroll\n"
             "    for (int m = 0; m < D; m++) { const real q = p[m] - Bd[m]; rr = rr + q * q; }\n    return rr > Bd[D];\n}\n\n");
