@@ -430,7 +430,8 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
     {
         /* a generation too small to give every workgroup a full window is cut into smaller ones: a window's rays are
          * shaded EU_WF_BLOCK at a time, so its latency (the kernel's critical path) shrinks with it */
-        const uint32_t win = total > gridDim.x * (EU_WF_WIN / 2) ? EU_WF_WIN : (total > gridDim.x * (EU_WF_WIN / 4) ? EU_WF_WIN / 2 : EU_WF_WIN / 4);
+        uint32_t win = EU_WF_WIN;      /* halved while the launch would leave workgroups without a window, down to one batch */
+        while (win > EU_WF_BLOCK && total <= gridDim.x * (win / 2)) win >>= 1;
         /* (Round 3 measured a dynamic deal of the windows through one counter per launch: equal at best -- 6211 vs 6219 Mray/s on 3d_room --
          * and 12 % slower on 3d_hallways when every workgroup's first window came from the counter too: 768 workgroups asking one address
          * at the same moment at the start of every launch.) */
