@@ -5,9 +5,12 @@ One "step" = one Environment::render pass: every pixel of the frame is traced by
 wavefront pipeline (intersect + shade per generation, resolve; scene, textures and the output frame resident in HBM; by default with
 kernels specialised for the scene, compiled when the renderer is created) and the
 RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.  Steps are issued round-robin to `--frames-in-flight`
-renderers (default 5), each with a stream and buffers of its own, so that consecutive frames overlap on the device the way the frame
+renderers (default 8), each with a stream and buffers of its own, so that consecutive frames overlap on the device the way the frame
 loop of the C ABI (eu_sequence_*) overlaps them; the timed region still holds exactly K whole frames between two device
-synchronisations, and `config.one_frame_alone` carries the time of a single frame with nothing else in flight.
+synchronisations, and `config.one_frame_alone` carries the time of a single frame with nothing else in flight.  The HIP runtime
+maps streams onto GPU_MAX_HW_QUEUES hardware queues (its default: 4); this script asks for 8 -- one per frame in flight -- unless the
+environment already says otherwise, and reports the value in `config.gpu_max_hw_queues` (8 frames on 4 queues: 8.2 Gray/s on config
+2, on 8 queues: 8.9; INTEGRATION.md tells a host how to set it).
 
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
   N > 1 : the frame grows with N (weak scaling: 1920x1080 pixels per GPU, aspect kept, same
@@ -28,6 +31,8 @@ import math
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything initialises HIP (see the docstring)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -63,8 +68,9 @@ def parse_args():
     ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
     ap.add_argument("--renderer-flags", type=int, default=0, help="eu_renderer_opts.flags")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 5: measured "
-                         "1 / 3 / 4 / 5 / 6 in flight = 6.1 / 6.6 / 7.3 / 7.6 / 7.1 Gray/s on config 2; 1 = one frame at a time on two band streams)")
+                    help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 8: measured "
+                         "5 / 8 / 12 in flight = 8.5 / 8.9 / 8.8 Gray/s on config 2 with 8 hardware queues, 8.0 / 8.2 / 8.4 with the runtime's 4; "
+                         "1 = one frame at a time on two band streams)")
     ap.add_argument("--abi-child", type=int, default=0,
                     help="internal: ONE process drives this many GPUs through the C ABI (eu_render_multi) on the 8K frame and prints a JSON object")
     return ap.parse_args()
@@ -378,7 +384,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 5
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 8
     band_streams = args.streams or (1 if in_flight > 1 else 0)      # frames in flight fill each other's kernel tails; a lone frame is cut into two bands for that
 
     def make_env():
@@ -534,7 +540,7 @@ def main():
             "config": {"workload": workload + (" low_precision (F = f32: a separate mode, not the headline)" if args.low_precision else ""), "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
-                       "frames_in_flight": in_flight, "band_streams_per_frame": band_streams or "library default (2 for this scene)",
+                       "frames_in_flight": in_flight, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "band_streams_per_frame": band_streams or "library default (2 for this scene)",
                        "one_frame_alone": {"ms": run["alone_ms"], "Mray/s": rays_per_step / run["alone_ms"] / 1e3, "kernel_ms": alone_kernel_ms,
                                            "note": "the same renderer with nothing else in flight (latency of one frame)"},
                        "slots_agree": run["slots_agree"],
