@@ -301,9 +301,9 @@ def other_configs(torch, dev, Parser, args, in_flight):
     steps each, so that the driver's record carries them too.  Same timing rule as the headline (device-resident, synchronised on both
     sides, the same number of frames in flight; two for the 8K frame, whose bands are 4 Mpixel each)."""
     out = []
-    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 20, False), ("4d_frame.json", 1920, 1080, 8, 20, False),
-                                          ("4d_cylinders.json", 1920, 1080, 8, 15, False), ("3d_room.json", 7680, 4320, 8, 4, False),
-                                          ("3d_room.json", 1920, 1080, 10, 20, False), ("3d_room.json", 1920, 1080, 8, 20, True)):
+    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 40, False), ("4d_frame.json", 1920, 1080, 8, 40, False),
+                                          ("4d_cylinders.json", 1920, 1080, 8, 32, False), ("3d_room.json", 7680, 4320, 8, 6, False),
+                                          ("3d_room.json", 1920, 1080, 10, 40, False), ("3d_room.json", 1920, 1080, 8, 40, True)):
         R = min(in_flight, 2) if W * H > (4 << 20) else in_flight
         envs = []
         for _ in range(R):
