@@ -59,7 +59,7 @@ class SceneInfo(C.Structure):
 class RendererOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("specialize", C.c_uint32), ("streams", C.c_uint32),
                 ("ray_factor", C.c_double), ("band_pixels", C.c_uint64), ("cache_dir", C.c_char_p), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32), ("jit_flags", C.c_char_p)]
+                ("reserved", C.c_uint32), ("jit_flags", C.c_char_p), ("band_grid_permille", C.c_uint32), ("split_pixels", C.c_uint32)]
 
 
 class JitInfo(C.Structure):
@@ -97,6 +97,7 @@ SYMBOLS = {
                                           C.c_size_t]),
     "eu_renderer_destroy": (None, [C.c_void_p]),
     "eu_renderer_jit_info": (C.c_int, [C.c_void_p, C.POINTER(JitInfo)]),
+    "eu_renderer_error": (C.c_char_p, [C.c_void_p]),
     "eu_scene_jit_source": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]),
     "eu_scene_jit_precompile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(JitInfo), C.c_char_p, C.c_size_t]),
     "eu_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
@@ -108,6 +109,7 @@ SYMBOLS = {
     "eu_renderer_retraces": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "eu_renderer_debug_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "eu_renderer_debug_generations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "eu_renderer_debug_wg_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "eu_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
                             C.POINTER(Stats)]),
     "eu_trace_screen_point": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_int32, C.c_int32,

@@ -45,6 +45,18 @@ __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *_
     }
 }
 
+/* start of a frame: the frame's counters and the work counters (trace_wavefront.h: WfDeal) of the bands and generations it will use --
+ * only the counter words themselves, each of which sits on a cache line of its own */
+__global__ void eu_wf_clear_kernel(EuDevCounters *counters, uint32_t *work, uint32_t words_per_band, uint32_t n_bands, uint32_t n_gen) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (uint32_t i = t; i < sizeof(EuDevCounters) / 8; i += nt) ((unsigned long long *)counters)[i] = 0ull;
+    const uint32_t per_gen = EU_WORK_SHARDS + 1u, per_band = n_gen * per_gen;
+    for (uint32_t i = t; i < n_bands * per_band; i += nt) {
+        const uint32_t band = i / per_band, r = i % per_band;
+        work[(size_t)band * words_per_band + (size_t)(r / per_gen) * EU_WORK_PER_GEN + (size_t)(r % per_gen) * EU_WORK_STRIDE] = 0u;
+    }
+}
+
 __global__ void eu_math_kernel(int fn, const eu_f64 *x, const eu_f64 *y, eu_f64 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -102,7 +114,11 @@ struct eu_renderer {
     std::string jit_log;
     std::shared_ptr<euclider::JitJob> jit_job;      /* EU_SPECIALIZE_ASYNC: the compilation in flight, polled when a frame is launched */
     /* wavefront pipeline buffers (HBM), sized for the largest frame seen so far */
-    static constexpr int WF_MAX_STREAMS = 4;
+    static constexpr int WF_MAX_STREAMS = 8;
+    static constexpr size_t kCountersPad = (sizeof(EuDevCounters) + 255) & ~(size_t)255;
+    static constexpr size_t kWorkWordsPerBand = (size_t)(EU_MAX_DEPTH + 1) * EU_WORK_PER_GEN;
+    static constexpr size_t counters_bytes(int bands) { return kCountersPad + (size_t)bands * kWorkWordsPerBand * 4 + kCountersPad; }      /* (+ a scratch EuDevCounters behind the last band) */
+    uint32_t *work_of(int band) const { return (uint32_t *)((char *)d_counters + kCountersPad) + (size_t)band * kWorkWordsPerBand; }
     EuWfBuffers wf[WF_MAX_STREAMS] = {};     /* band pipelines run concurrently on side streams */
     size_t wf_pixels = 0;
     uint32_t wf_depth = 0;                   /* deepest max_depth the node slots are sized for */
@@ -115,6 +131,9 @@ struct eu_renderer {
     int wf_n_streams = 2;
     real wf_ray_factor = R(4.0);
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass */
+    uint64_t wf_split_pixels = 1u << 19;     /* frames of at least this many pixels are cut into wf_n_streams concurrent bands */
+    uint32_t wf_permille = 0;                /* the share of a full-chip grid the buffers' queue segments were cut for */
+    unsigned long long *d_prof = nullptr;    /* diagnostics: per-workgroup time stamps of kernels built with -DEU_PROFILE_WG */
     std::vector<void *> wf_allocs;
     std::string err;
 };
@@ -247,6 +266,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         r->wf_n_streams = r->opts.streams ? (int)r->opts.streams : ((h.flags & 1u) ? 2 : 1);      /* branching scenes: two band pipelines fill each other's kernel tails (measured: +8 %); others: -5 % */
         if (r->opts.ray_factor > 0.0) r->wf_ray_factor = (real)r->opts.ray_factor;
         if (r->opts.band_pixels) r->wf_band_pixels = r->opts.band_pixels;
+        if (r->opts.split_pixels) r->wf_split_pixels = r->opts.split_pixels;
         uint32_t specialize = r->opts.specialize;
 #ifdef EU_DIAGNOSTICS      /* profiling scripts only: the shipped library reads no environment variable here */
         if (const char *k = getenv("EU_KERNEL")) r->use_wavefront = std::string(k) != "mega" && std::string(k) != "stack";
@@ -257,8 +277,9 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
 #endif
         HIP_TRY(hipMalloc((void **)&r->d_scene, blob.size() * 8));
         HIP_TRY(hipMemcpy(r->d_scene, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&r->d_counters, sizeof(EuDevCounters)));
-        HIP_TRY(hipMemset(r->d_counters, 0, sizeof(EuDevCounters)));
+        /* the frame's counters and, behind them, the work counters of every band pipeline (trace_wavefront.h: WfDeal): one clear per frame */
+        HIP_TRY(hipMalloc((void **)&r->d_counters, eu_renderer::counters_bytes(eu_renderer::WF_MAX_STREAMS)));
+        HIP_TRY(hipMemset(r->d_counters, 0, eu_renderer::counters_bytes(eu_renderer::WF_MAX_STREAMS)));
         HIP_TRY(hipDeviceSynchronize());      /* (hipMemset is asynchronous to the host; see wf_ensure) */
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
@@ -279,6 +300,8 @@ extern "C" int eu_renderer_create_opts(const eu_scene *scene, int device, const 
 extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer **out, char *err, size_t errlen) {
     return eu_renderer_create_opts(scene, device, nullptr, out, err, errlen);
 }
+
+extern "C" const char *eu_renderer_error(const eu_renderer *r) { return r ? r->err.c_str() : ""; }
 
 extern "C" int eu_renderer_jit_info(eu_renderer *r, eu_jit_info *out) {
     if (!r || !out) return EU_ERR_INVALID_ARGUMENT;
@@ -302,6 +325,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (r->d_rgb) (void)hipFree(r->d_rgb);
     if (r->d_hit) (void)hipFree(r->d_hit);
     if (r->d_point) (void)hipFree(r->d_point);
+    if (r->d_prof) (void)hipFree(r->d_prof);
     if (r->d_path_in) (void)hipFree(r->d_path_in);
     if (r->d_path_out) (void)hipFree(r->d_path_out);
     for (int i = 0; i < eu_renderer::EV_RING; i++) { if (r->ev_start[i]) (void)hipEventDestroy(r->ev_start[i]); if (r->ev_stop[i]) (void)hipEventDestroy(r->ev_stop[i]); }
@@ -351,8 +375,10 @@ static hipError_t launch_trace(eu_renderer *r, hipStream_t stream, const EuDevCa
 
 
 /* ------------------------------------------------------------------ wavefront pipeline (trace_wavefront.h) */
-static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_depth, int n_sets) {
-    if (pixels <= r->wf_pixels && max_depth <= r->wf_depth && n_sets <= r->wf_sets && items <= (size_t)r->wf[0].ray_cap) return EU_OK;
+static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_depth, int n_sets, uint32_t permille) {
+    if (pixels <= r->wf_pixels && max_depth <= r->wf_depth && n_sets <= r->wf_sets && items <= (size_t)r->wf[0].ray_cap && (permille == 0 || permille == r->wf_permille)) return EU_OK;
+    if (permille == 0) permille = r->wf_permille ? r->wf_permille : 1000u;      /* (a single pixel takes the buffers as they are) */
+    r->wf_permille = permille;
     if (pixels < r->wf_pixels) pixels = r->wf_pixels;
     if (max_depth > r->wf_depth) r->wf_depth = max_depth;
     if (n_sets > r->wf_sets) r->wf_sets = n_sets;      /* the second buffer set exists only once a frame is traced as two concurrent bands */
@@ -367,6 +393,8 @@ static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_d
     /* one queue segment per producer workgroup; a generation's queue holds n_seg * seg_cap ray slots */
     uint32_t n_seg = (uint32_t)r->num_cus * r->wf_seg_per_cu;
     if (n_seg > EU_WF_MAX_SEG) n_seg = EU_WF_MAX_SEG;
+    n_seg = (uint32_t)(((uint64_t)n_seg * permille + 999) / 1000 + 7u) & ~7u;      /* one band pipeline's share of the chip (wf_launch_frame) */
+    if (n_seg < 8) n_seg = 8;
     if (pixels / 16 < n_seg) n_seg = pixels / 16 < 16 ? 16u : (uint32_t)(pixels / 16);      /* tiny frames, single pixels: fewer producers, small buffers */
     size_t seg_cap = ((size_t)((real)pixels * r->wf_ray_factor) + n_seg - 1) / n_seg;
     if (seg_cap < 1024) seg_cap = 1024;        /* small frames: absorb uneven segments */
@@ -397,6 +425,8 @@ static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_d
     HIP_TRY(hipDeviceSynchronize());
     B.ray_cap = (uint32_t)ray_cap; B.node_cap = (uint32_t)node_cap;
     B.n_seg = n_seg; B.seg_cap = (uint32_t)seg_cap;
+    B.prof = r->d_prof;
+    B.work = r->work_of(set);
     }
 
     if (!r->wf_stream[0]) {
@@ -424,27 +454,44 @@ static int wf_grid_module(eu_renderer *r, hipFunction_t f, size_t lds_bytes, uns
 
 template <int D>
 static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDevCamera &dc, const EuDevFrame &df_in, uint32_t *rgba, eu_f64 *hit_t, eu_f64 *point) {
-    /* Large frames are traced in bands of whole 8-row tiles so that the queue and node buffers stay bounded
-     * (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes). */
+    /* A frame is traced as BANDS of whole 8-row tiles.  Frames above `band_pixels` need them so that the queue and node buffers stay
+     * bounded (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes); smaller frames are cut into
+     * `wf_n_streams` bands that run as independent pipelines on streams of their own, so that one band's dependent launches -- each
+     * ending in a tail during which most of the chip idles -- are covered by the other bands' kernels.  Every band launches a share
+     * of a full-chip grid (`band_grid_permille`): together the bands oversubscribe the chip, which is what fills the tails. */
     uint32_t band_rows = df_in.local_rows;
-    bool two_streams = false;
+    int n_par = 1;                  /* band pipelines in flight */
     if (!df_in.single_pixel) {
         uint64_t rows_fit = r->wf_band_pixels / (df_in.width ? df_in.width : 1);
         rows_fit = rows_fit / 8 * 8;
         if (rows_fit < 8) rows_fit = 8;
         if (rows_fit < band_rows) band_rows = (uint32_t)rows_fit;
-        /* at least two bands for anything but tiny frames: they run on two streams, so the tail and the launch gap
-         * of one band's kernel are filled by the other band's kernel */
-        if ((uint64_t)df_in.local_rows * df_in.width >= (1u << 19) && r->wf_n_streams > 1) {
-            const uint32_t ns = (uint32_t)r->wf_n_streams;
+        if ((uint64_t)df_in.local_rows * df_in.width >= r->wf_split_pixels && r->wf_n_streams > 1) {
+            uint32_t ns = (uint32_t)r->wf_n_streams;
+            while (ns > 1 && (uint64_t)df_in.local_rows * df_in.width / ns < r->wf_split_pixels / 2) ns--;      /* bands stay large enough to be worth a launch chain */
             const uint32_t part = (((df_in.local_rows + ns - 1) / ns) + 7) / 8 * 8;
             if (part < band_rows) band_rows = part;
-            two_streams = true;
+            n_par = (int)ns;
         }
     }
+    const uint32_t n_bands = df_in.single_pixel ? 1u : (df_in.local_rows + band_rows - 1) / band_rows;
+    if ((uint32_t)n_par > n_bands) n_par = (int)n_bands;
+    const bool side_streams = n_par > 1;
+    /* Concurrent bands of ONE round take the frame's 8-row groups in turn (band b: groups b, b + n, ...): contiguous halves of 3d_room
+     * differed by 60 % in work (the glass objects sit in the lower half) and the lighter band's pipeline idled while the other finished
+     * (profiles/r04_wg_profile_two_bands.txt).  Frames that need several rounds (bounded buffers) keep contiguous bands. */
+    const bool interleaved = side_streams && n_bands == (uint32_t)n_par && !df_in.single_pixel;
+    const uint32_t n_groups = (df_in.local_rows + 7) / 8;
+    std::vector<uint32_t> band_begin(n_bands + 1);
+    for (uint32_t b = 0; b <= n_bands; b++) { const uint64_t r0 = (uint64_t)b * band_rows; band_begin[b] = r0 < df_in.local_rows ? (uint32_t)r0 : df_in.local_rows; }
+    if (interleaved) band_rows = ((n_groups + (uint32_t)n_par - 1) / (uint32_t)n_par) * 8;      /* (the largest band: what the buffers are sized for) */
     const size_t band_pixels = (size_t)band_rows * df_in.width;
     const size_t band_items = df_in.single_pixel ? 64 : (size_t)df_in.tiles_x * ((band_rows + 7) / 8) * 64;      /* generation 0: one slot per item of the band's 8x8 tiles */
-    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, band_items, dc.max_depth, two_streams ? r->wf_n_streams : 1);
+    /* the share of a full-chip grid one band pipeline launches */
+    uint32_t permille = 1000;
+    if (side_streams) permille = r->opts.band_grid_permille ? r->opts.band_grid_permille : (uint32_t)(2000 / n_par < 250 ? 250 : (2000 / n_par > 1000 ? 1000 : 2000 / n_par));
+    if (permille > 1000) permille = 1000;
+    int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, band_items, dc.max_depth, n_par, df_in.single_pixel ? 0u : permille);
     if (rc != EU_OK) return rc;
     if (r->prepare_only) return EU_OK;      /* buffers, streams and events exist now: nothing is allocated while the frame is in flight */
     const bool jit = r->jit_intersect != nullptr;
@@ -464,65 +511,94 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 96>, 0, g_isect0))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 0>, isect_lds, g_isect0))) return rc;
     if ((rc = wf_grid(r, eu_wf_resolve_kernel, 0, g_res))) return rc;
-    if (two_streams) {      /* fork: both side streams wait for everything queued on the caller's stream so far */
+    auto share = [&](unsigned g) { unsigned v = (unsigned)(((uint64_t)g * permille + 999) / 1000); v = (v + 7u) & ~7u; return v < 8u ? 8u : v; };      /* multiples of 8: every XCD gets the same number */
+    g_isect = share(g_isect); g_isect0 = share(g_isect0); g_res = share(g_res);
+    if (side_streams) {      /* fork: the side streams wait for everything queued on the caller's stream so far */
         HIP_TRY(hipEventRecord(r->wf_fork, caller_stream));
-        for (int k = 0; k < r->wf_n_streams; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
+        for (int k = 0; k < n_par; k++) HIP_TRY(hipStreamWaitEvent(r->wf_stream[k], r->wf_fork, 0));
     }
-    uint32_t band_no = 0;
-    for (uint32_t row0 = 0; row0 < df_in.local_rows; row0 += band_rows, band_no++) {
-        EuDevFrame df = df_in;
-        const int set = two_streams ? (int)(band_no % (uint32_t)r->wf_n_streams) : 0;
-        hipStream_t stream = two_streams ? r->wf_stream[set] : caller_stream;
-        EuWfBuffers B = r->wf[set];
-        if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; B.npix = 1u; }
-        else {
-            df.band_row0 = row0;
-            df.band_rows = df_in.local_rows - row0 < band_rows ? df_in.local_rows - row0 : band_rows;
-            df.root_base = row0 * df.width;
-            df.n_tiles = df.tiles_x * ((df.band_rows + 7) / 8);
-            B.npix = df.band_rows * df.width;
+    const uint64_t *scene = r->d_scene;
+    EuDevCounters *counters = r->d_counters;
+    EuDevCamera cam = dc;
+    const uint32_t n_gen = dc.max_depth ? dc.max_depth : 1u;      /* depth 0: generation 0 only marks its pixels and samples the background */
+    uint32_t max_depth = dc.max_depth;
+    /* rounds of n_par bands; inside a round the launches are issued generation by generation across the bands, so that every band's
+     * pipeline starts at once (band after band, the last band's first kernel would wait for the host to issue everything before it) */
+    for (uint32_t band0 = 0; band0 < n_bands; band0 += (uint32_t)n_par) {
+        const uint32_t nb = n_bands - band0 < (uint32_t)n_par ? n_bands - band0 : (uint32_t)n_par;
+        EuDevFrame dfs[eu_renderer::WF_MAX_STREAMS];
+        EuWfBuffers Bs[eu_renderer::WF_MAX_STREAMS];
+        hipStream_t sts[eu_renderer::WF_MAX_STREAMS];
+        uint32_t total0s[eu_renderer::WF_MAX_STREAMS];
+        for (uint32_t k = 0; k < nb; k++) {
+            EuDevFrame &df = dfs[k];
+            df = df_in;
+            const uint32_t row0 = band_begin[band0 + k], row1 = band_begin[band0 + k + 1];
+            sts[k] = side_streams ? r->wf_stream[k] : caller_stream;
+            Bs[k] = r->wf[side_streams ? k : 0];
+            Bs[k].pad = band0 + k;
+            if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; Bs[k].npix = 1u; }
+            else if (interleaved) {
+                const uint32_t groups = (n_groups - k + (uint32_t)n_par - 1) / (uint32_t)n_par;      /* groups k, k + n, ... < n_groups */
+                df.band_row0 = k; df.band_stride = (uint32_t)n_par;
+                df.band_rows = groups * 8;
+                df.root_base = 0;
+                df.n_tiles = df.tiles_x * groups;
+                Bs[k].npix = df.band_rows * df.width;
+            } else {
+                df.band_row0 = row0;
+                df.band_rows = row1 - row0;
+                df.root_base = row0 * df.width;
+                df.n_tiles = df.tiles_x * ((df.band_rows + 7) / 8);
+                Bs[k].npix = df.band_rows * df.width;
+            }
+            if ((size_t)df.n_tiles * 64 > (size_t)Bs[k].ray_cap) { r->err = "internal: generation 0 does not fit its queue"; return EU_ERR_CAPACITY; }
+            total0s[k] = df.n_tiles * 64u;
+            if (band0 > 0)      /* (the frame's first round was cleared with the counters; a cleared EuDevCounters would lose the frame's sums: the scratch block behind the last band takes that part) */
+                hipLaunchKernelGGL(eu_wf_clear_kernel, dim3(1), dim3(256), 0, sts[k], (EuDevCounters *)r->work_of(eu_renderer::WF_MAX_STREAMS), Bs[k].work, (uint32_t)eu_renderer::kWorkWordsPerBand, 1u, n_gen + 1u);
         }
-        if ((size_t)df.n_tiles * 64 > (size_t)B.ray_cap) { r->err = "internal: generation 0 does not fit its queue"; return EU_ERR_CAPACITY; }
-        const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
-        EuDevCamera cam = dc;
-        uint32_t total0 = df.n_tiles * 64u;
-        const uint64_t *scene = r->d_scene;
-        EuDevCounters *counters = r->d_counters;
-        const uint32_t n_gen = dc.max_depth ? dc.max_depth : 1u;      /* depth 0: generation 0 only marks its pixels and samples the background */
-        uint32_t max_depth = dc.max_depth;
-        real time_s = df.time_s;
         for (uint32_t g = 0; g < n_gen; g++) {
             uint32_t gen = g;
-            if (jit && g == 0) {
-                void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&hit_t};
-                HIP_TRY(hipModuleLaunchKernel(r->jit_intersect0, g_isect0, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
-                void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
-                HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
-            } else if (jit) {
-                void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&gen, (void *)&B, (void *)&counters};
-                HIP_TRY(hipModuleLaunchKernel(r->jit_intersect, g_isect, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
-                void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
-                HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
-            } else if (g == 0) {
-                if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 0>), dim3(g_isect0), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, cam, df, B, counters, hit_t);
-                else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 16>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, cam, df, B, counters, hit_t);
-                else hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 96>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, cam, df, B, counters, hit_t);
-                if (shade_lds) hipLaunchKernelGGL((eu_wf_shade0_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
-                else hipLaunchKernelGGL((eu_wf_shade0_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
-            } else {
-                if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, gen, B, counters);
-                else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, gen, B, counters);
-                else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, gen, B, counters);
-                if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
-                else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+            for (uint32_t k = 0; k < nb; k++) {
+                EuDevFrame &df = dfs[k];
+                EuWfBuffers &B = Bs[k];
+                hipStream_t stream = sts[k];
+                const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
+                real time_s = df.time_s;
+                if (jit && g == 0) {
+                    void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&hit_t};
+                    HIP_TRY(hipModuleLaunchKernel(r->jit_intersect0, g_isect0, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
+                    void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
+                    HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                } else if (jit) {
+                    void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&gen, (void *)&B, (void *)&counters};
+                    HIP_TRY(hipModuleLaunchKernel(r->jit_intersect, g_isect, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
+                    void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
+                    HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                } else if (g == 0) {
+                    if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 0>), dim3(g_isect0), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, cam, df, B, counters, hit_t);
+                    else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 16>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, cam, df, B, counters, hit_t);
+                    else hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 96>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, cam, df, B, counters, hit_t);
+                    if (shade_lds) hipLaunchKernelGGL((eu_wf_shade0_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
+                    else hipLaunchKernelGGL((eu_wf_shade0_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
+                } else {
+                    if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, gen, B, counters);
+                    else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, gen, B, counters);
+                    else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, gen, B, counters);
+                    if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+                    else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+                }
             }
         }
+        /* bottom-up: the nodes that wait for two children (trace_nodes.h); a scene none of whose surfaces reflects has none */
+        if (!(r->flat->header().flags & 4u))
         for (uint32_t g = n_gen; g-- > 0;)
-            hipLaunchKernelGGL(eu_wf_resolve_kernel, dim3(g_res), dim3(EU_WF_BLOCK), 0, stream, g, total0, B, counters, rgba, point);
-        if (df.single_pixel) break;
+            for (uint32_t k = 0; k < nb; k++)
+                hipLaunchKernelGGL(eu_wf_resolve_kernel, dim3(g_res), dim3(EU_WF_BLOCK), 0, sts[k], g, total0s[k], Bs[k], counters, rgba, point);
+        if (df_in.single_pixel) break;
     }
-    if (two_streams) {      /* join */
-        for (int k = 0; k < r->wf_n_streams; k++) { HIP_TRY(hipEventRecord(r->wf_join[k], r->wf_stream[k])); HIP_TRY(hipStreamWaitEvent(caller_stream, r->wf_join[k], 0)); }
+    if (side_streams) {      /* join */
+        for (int k = 0; k < n_par; k++) { HIP_TRY(hipEventRecord(r->wf_join[k], r->wf_stream[k])); HIP_TRY(hipStreamWaitEvent(caller_stream, r->wf_join[k], 0)); }
     }
     HIP_TRY(hipGetLastError());
     return EU_OK;
@@ -558,7 +634,11 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
         if (r->use_wavefront) return (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
         return EU_OK;
     }
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, sizeof(EuDevCounters), stream));
+    {
+        const uint32_t nb = r->use_wavefront ? (uint32_t)(r->wf_n_streams > 1 ? r->wf_n_streams : 1) : 0u;
+        const uint32_t ng = (cam->max_depth ? cam->max_depth : 1u) + 1u;
+        hipLaunchKernelGGL(eu_wf_clear_kernel, dim3(nb ? 4 : 1), dim3(256), 0, stream, r->d_counters, r->work_of(0), (uint32_t)eu_renderer::kWorkWordsPerBand, nb, ng);
+    }
     const int slot = (int)(r->launches % eu_renderer::EV_RING);
     HIP_TRY(hipEventRecord(r->ev_start[slot], stream));
     hipError_t e = hipSuccess;
@@ -585,6 +665,15 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     return EU_OK;
 }
 
+/* why the wavefront pipeline could not finish a frame ("" = it could) */
+static std::string unfinished_reason(const EuDevCounters &c) {
+    if (c.overflow) return "ray queue overflow (" + std::to_string(c.overflow) + " rays dropped): raise eu_renderer_opts.ray_factor or render in row tiles";
+    if (c.hs_full) return "hit stack full for " + std::to_string(c.hs_full) + " rays (the wavefront kernels reserve two hits per convex chain; rounding let a third through): "
+                          "only the stack kernel finishes this frame -- eu_render, eu_trace_screen_point, eu_sequence_next and eu_render_multi fall back to it by themselves, "
+                          "eu_render_device callers use a renderer created with EU_KERNEL_STACK";
+    return std::string();
+}
+
 /* A frame whose recursion fans out beyond the queues' capacity (more than ray_factor rays per pixel in one generation) cannot be
  * finished by the wavefront pipeline; the persistent stack-based kernel needs O(depth) memory per lane whatever the fan-out, so
  * the synchronous entry points trace such a frame again with it.  Waits for the frame; *retraced says whether that happened. */
@@ -595,7 +684,7 @@ static int retrace_if_overflowed(eu_renderer *r, const eu_camera *cam, const eu_
     HIP_TRY(hipStreamSynchronize(stream));
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    if (!c.overflow) return EU_OK;
+    if (!c.overflow && !c.hs_full) return EU_OK;
     r->use_wavefront = false;
     r->retraces++;
     const int rc = render_device_impl(r, cam, f, stream, rgba, hit_t, nullptr);
@@ -635,7 +724,7 @@ extern "C" int eu_renderer_stats(eu_renderer *r, eu_stats *out) {
     EuDevCounters c;
     HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c.rays; out->bg_samples = c.bg_samples; out->nan_pixels = c.nan_pixels; out->errors = c.errors;
-    if (c.overflow) { r->err = "wavefront queue overflow (" + std::to_string(c.overflow) + " rays dropped): raise eu_renderer_opts.ray_factor or render in row tiles"; return EU_ERR_CAPACITY; }
+    if (c.overflow || c.hs_full) { r->err = unfinished_reason(c); return EU_ERR_CAPACITY; }
     return EU_OK;
 }
 
@@ -659,6 +748,32 @@ extern "C" int eu_renderer_debug_generations(eu_renderer *r, unsigned long long 
     std::vector<uint32_t> h((size_t)(EU_MAX_DEPTH + 2) * B.n_seg);
     HIP_TRY(hipMemcpy(h.data(), B.seg_count, h.size() * 4, hipMemcpyDeviceToHost));
     for (int g = 0; g < 17 && g < EU_MAX_DEPTH + 2; g++) for (uint32_t i = 0; i < B.n_seg; i++) out[g] += h[(size_t)g * B.n_seg + i];      /* (generation 0 has no queue: out[0] stays 0) */
+    return EU_OK;
+}
+
+/* Diagnostics (kernels built with -DEU_PROFILE_WG): the first call (out == NULL) switches the recording on; later calls wait for the
+ * device, copy up to max_records records of four words each (trace_wavefront.h: WF_PROF_END) and start a new recording. */
+extern "C" int eu_renderer_debug_wg_profile(eu_renderer *r, unsigned long long *out, size_t max_records, size_t *n_records) {
+    if (!r) return EU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t cap = (size_t)1 << 20;      /* EU_PROF_CAP */
+    if (!r->d_prof) {
+        HIP_TRY(hipMalloc((void **)&r->d_prof, (4 + 4 * cap) * 8));
+        HIP_TRY(hipMemset(r->d_prof, 0, 32));
+        HIP_TRY(hipDeviceSynchronize());
+        for (int k = 0; k < eu_renderer::WF_MAX_STREAMS; k++) r->wf[k].prof = r->d_prof;
+        if (n_records) *n_records = 0;
+        return EU_OK;
+    }
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, r->d_prof, 8, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    if (n > max_records) n = max_records;
+    if (out && n) HIP_TRY(hipMemcpy(out, r->d_prof + 4, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (n_records) *n_records = (size_t)n;
+    HIP_TRY(hipMemset(r->d_prof, 0, 32));
+    HIP_TRY(hipDeviceSynchronize());
     return EU_OK;
 }
 
@@ -731,6 +846,17 @@ extern "C" int eu_trace_screen_point(eu_renderer *r, const eu_camera *cam, const
     one.row_begin = (uint32_t)y; one.row_end = (uint32_t)y + 1;
     rc = render_device_impl(r, cam, &one, nullptr, r->d_rgba, nullptr, r->d_point, true, (uint32_t)x);
     if (rc != EU_OK) return rc;
+    if (r->use_wavefront) {      /* a ray dropped from a full queue or hit stack would leave a colour made of what was left: trace the pixel again with the stack kernel */
+        EuDevCounters c;
+        HIP_TRY(hipMemcpy(&c, r->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        if (c.overflow || c.hs_full) {
+            r->use_wavefront = false;
+            r->retraces++;
+            rc = render_device_impl(r, cam, &one, nullptr, r->d_rgba, nullptr, r->d_point, true, (uint32_t)x);
+            r->use_wavefront = true;
+            if (rc != EU_OK) return rc;
+        }
+    }
     HIP_TRY(hipMemcpy(rgb, r->d_point, 3 * sizeof(eu_f64), hipMemcpyDeviceToHost));
     return EU_OK;
 }
@@ -753,6 +879,7 @@ struct eu_sequence {
         uint8_t *h_rgb = nullptr; EuDevCounters *h_cnt = nullptr;        /* h_rgb: the pinned image this submit copies into (one of host_rgb) */
         hipEvent_t traced = nullptr, copied = nullptr;
         uint32_t width = 0, rows = 0;
+        eu_camera cam; eu_frame f;      /* the frame in this slot: one the wavefront pipeline cannot finish is traced again when it is collected */
     };
     std::vector<Slot> slots;
     /* slots + 1 pinned images, used round-robin by submit number: the image handed out by eu_sequence_next stays untouched
@@ -847,6 +974,7 @@ extern "C" int eu_sequence_submit(eu_sequence *q, const eu_camera *cam, const eu
     HIP_TRY(hipMemcpyAsync(s.h_cnt, s.d_cnt, sizeof(EuDevCounters), hipMemcpyDeviceToHost, q->copy_stream));
     HIP_TRY(hipEventRecord(s.copied, q->copy_stream));
     s.width = f->width; s.rows = rows;
+    s.cam = *cam; s.f = *f;
     q->submitted++;
     return EU_OK;
 }
@@ -856,15 +984,33 @@ extern "C" int eu_sequence_next(eu_sequence *q, const uint8_t **rgb_host, uint32
     eu_renderer *r = q->r;
     if (q->taken == q->submitted) { r->err = "no frame in flight"; return EU_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(r->device));
-    eu_sequence::Slot &s = q->slots[q->taken % q->slots.size()];
+    const size_t slot_no = q->taken % q->slots.size();
+    eu_sequence::Slot &s = q->slots[slot_no];
     HIP_TRY(hipEventSynchronize(s.copied));
     q->taken++;
     *rgb_host = s.h_rgb;
     if (width) *width = s.width;
     if (rows) *rows = s.rows;
     const EuDevCounters *hc = s.h_cnt;
+    eu_renderer *rs = q->slot_renderer[slot_no];
+    if ((hc->overflow || hc->hs_full) && rs->use_wavefront) {
+        /* the wavefront pipeline dropped rays (full queue or hit stack): this frame is traced again by the stack kernel, as eu_render
+         * does -- behind whatever this slot's stream holds, synchronously: the slow path, visible as eu_renderer_retraces */
+        hipStream_t st = q->slot_stream[slot_no];
+        const size_t pixels = (size_t)s.rows * s.width;
+        rs->use_wavefront = false;
+        r->retraces++;
+        int rc = render_device_impl(rs, &s.cam, &s.f, st, s.d_rgba, nullptr, nullptr);
+        rs->use_wavefront = true;
+        if (rc != EU_OK) { if (rs != r) r->err = rs->err; return rc; }
+        rc = eu_pack_rgb_device(rs, s.d_rgba, s.d_rgb, pixels, st);
+        if (rc != EU_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_rgb, s.d_rgb, pixels * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s.h_cnt, rs->d_counters, sizeof(EuDevCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     if (stats) { stats->rays = hc->rays; stats->bg_samples = hc->bg_samples; stats->nan_pixels = hc->nan_pixels; stats->errors = hc->errors; }
-    if (hc->overflow) { r->err = "ray queue overflow: raise eu_renderer_opts.ray_factor or render in row tiles"; return EU_ERR_CAPACITY; }
+    if (hc->overflow || hc->hs_full) { r->err = unfinished_reason(*hc); return EU_ERR_CAPACITY; }
     return EU_OK;
 }
 
@@ -1126,7 +1272,7 @@ extern "C" int eu_render_multi_end(eu_multi *m, uint8_t *rgb_host, void **rgb_de
         if (s.lrows[k] == 0) continue;
         int rc = counters_of(k);
         if (rc != EU_OK) return rc;
-        if (!c[k].overflow || !m->r[k]->use_wavefront) continue;
+        if ((!c[k].overflow && !c[k].hs_full) || !m->r[k]->use_wavefront) continue;
         eu_renderer *r = m->r[k];
         r->use_wavefront = false;
         r->retraces++;
@@ -1152,7 +1298,7 @@ extern "C" int eu_render_multi_end(eu_multi *m, uint8_t *rgb_host, void **rgb_de
     eu_stats sum = {0, 0, 0, 0};
     for (uint32_t k = 0; k < n; k++) {
         if (s.lrows[k] == 0) continue;
-        if (c[k].overflow) { m->err = "ray queue overflow on device " + std::to_string(m->devices[k]) + " that the stack kernel did not take over"; worst = EU_ERR_CAPACITY; continue; }
+        if (c[k].overflow || c[k].hs_full) { m->err = "device " + std::to_string(m->devices[k]) + ": " + unfinished_reason(c[k]) + " (the stack kernel did not take over)"; worst = EU_ERR_CAPACITY; continue; }
         sum.rays += c[k].rays; sum.bg_samples += c[k].bg_samples; sum.nan_pixels += c[k].nan_pixels; sum.errors += c[k].errors;
     }
     if (stats && worst == EU_OK) *stats = sum;      /* (never partially summed) */

@@ -766,9 +766,18 @@ struct Flattener {
             if (!(l.signum == R(1.0) || l.signum == -R(1.0))) return 0;      /* (the device compares sign bits, chain_matrices_box) */
         }
         /* (zero constants: 3-D only -- the 4-D kernels sit at their register limit and pay for the second variant with spills) */
-        return zero_c ? ((D != 3 || getenv("EU_NO_BOX0_CHAINS")) ? 0 : 2) : 1;
+        return zero_c ? ((D != 3 || diag_env("EU_NO_BOX0_CHAINS")) ? 0 : 2) : 1;
     }
-    static bool no_box_chains() { static const bool v = getenv("EU_NO_BOX_CHAINS") != nullptr; return v; }      /* A/B diagnostics */
+    /* A/B diagnostics: only a -DEU_DIAGNOSTICS build reads the environment (the shipped library reads none but the cache directory's) */
+    static bool diag_env(const char *name) {
+#ifdef EU_DIAGNOSTICS
+        return getenv(name) != nullptr;
+#else
+        (void)name;
+        return false;
+#endif
+    }
+    static bool no_box_chains() { static const bool v = diag_env("EU_NO_BOX_CHAINS"); return v; }
 
     void push_halfspace_params(const Shape &s) {
         for (int i = 0; i < D; i++) params.push_back(s.a[i]);
@@ -784,7 +793,7 @@ struct Flattener {
     }
 
     /* returns (max list length of the node's stream); tracks the simulated hit-stack */
-    static bool no_guards() { static const bool v = getenv("EU_NO_SKIP_OPS") != nullptr; return v; }      /* A/B diagnostics */
+    static bool no_guards() { static const bool v = diag_env("EU_NO_SKIP_OPS"); return v; }
     HitUse emit_shape(const Shape &s, HitUse base_use, uint32_t depth, bool is_root = false, real parent_r = INFINITY) {
         if (s.dim != D) fail(ParserError::CustomError, "shape dimension does not match the universe");
         EuShapeOp op{};
@@ -1191,6 +1200,13 @@ FlatScene flatten(const Universe &u) {
      * possible): the recursion tree branches and a frame holds several times more rays than pixels */
     for (auto &fs : f.surfaces)
         if (fs.ratio_kind == EU_RATIO_FRESNEL || (fs.ratio_p0 > R(0.0) && fs.ratio_p0 < R(1.0))) h.flags |= 1u;
+    /* flags bit 2: NO surface ever asks for a reflection (every ratio provider is the uniform one with a ratio that is not > 0; surface.rs:
+     * 119-139, 200-211): then no node of the recursion tree waits for two children and the renderer launches no resolve passes */
+    {
+        bool reflects = false;
+        for (auto &fs : f.surfaces) if (fs.ratio_kind != EU_RATIO_UNIFORM || !(fs.ratio_p0 <= R(0.0))) reflects = true;
+        if (!reflects) h.flags |= 4u;
+    }
     h.n_words = (uint32_t)w.size();
     memcpy(w.data(), &h, sizeof h);
     out.textures = f.textures;

@@ -46,7 +46,8 @@ struct EuDevFrame {
     uint32_t tiles_x, n_tiles, debug_crosshair, single_pixel;
     uint32_t single_x, single_y;
     uint32_t local_rows, strip_count, strip_index, pad;   /* rows in the output buffer; interleaved-strip partition */
-    uint32_t band_row0, band_rows, root_base, pad2;        /* wavefront: the band of local rows traced by this pass; root_base = band_row0 * width */
+    uint32_t band_row0, band_rows, root_base, band_stride;        /* wavefront: the band of local rows traced by this pass; root_base = band_row0 * width.
+                                                                   * band_stride > 1: the band is every band_stride-th group of 8 rows, starting with group band_row0 */
     real time_s;          /* time_millis, d3/entity/surface.rs:32 */
 };
 
@@ -56,7 +57,7 @@ struct EuDevCounters {      /* device memory, zeroed before each launch */
     unsigned long long phase[16];  /* diagnostic builds only */
     unsigned long long gen_count[EU_MAX_DEPTH + 2];   /* wavefront pipeline: rays queued per generation */
     unsigned long long overflow;                      /* rays / nodes dropped because a queue was full */
-    unsigned long long node_chunks;                   /* (unused) */
+    unsigned long long hs_full;                       /* rays whose hit stack (the wavefront kernels' soft bound, EU_CNT_HS_FULL) was full: only the stack kernel can finish such a frame */
 };
 
 /* ------------------------------------------------------------------ scene view */
@@ -374,7 +375,7 @@ struct LaneCounters { uint32_t rays, bg, nan_px, errors; };
 #endif
 
 /* bit 30 of LaneCounters::errors: this lane's hit stack was full (the wavefront kernels reserve the `soft` number of entries,
- * scene_host.cpp: HitUse).  The kernel's counter flush turns it into EuDevCounters::overflow and the frame is traced again by the
+ * scene_host.cpp: HitUse).  The kernel's counter flush turns it into EuDevCounters::hs_full and the frame is traced again by the
  * stack kernel, whose stack has the strict size. */
 #define EU_CNT_HS_FULL 0x40000000u
 
@@ -746,9 +747,17 @@ template <int D> EU_DEV bool ray_misses_bound(const real *Bd, const real *o, con
 /* t_k of a chain's leaf `idx`, picked with compares (for a hit stack in private memory: staging the t_k through it, as the LDS form
  * does, is eight scratch stores and a dependent load per chain -- 4d_frame wrote 0.7 GB per frame that way) */
 EU_DEV real chain_pick_t(const real (&tk)[EU_CHAIN_MAX], uint32_t count, uint32_t idx) {
+    /* a chain of selects over VALUES: every t_k passes through an (empty) asm statement first, otherwise the optimiser turns the
+     * selects into ONE load from a select of addresses, the array stays in scratch memory, and every such load sits behind an
+     * `s_waitcnt vmcnt(0)` in the middle of the ray loop -- which also waits for the next ray's prefetch (round 4: 80 bytes of
+     * scratch and three such waits per ray batch in 3d_room's intersect kernel) */
     real t = tk[0];
 #pragma unroll
-    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (k < count) t = (idx == k) ? tk[k] : t;
+    for (uint32_t k = 1; k < EU_CHAIN_MAX; k++) if (k < count) {
+        real x = tk[k];
+        asm("" : "+v"(x));
+        t = (idx == k) ? x : t;
+    }
     return t;
 }
 

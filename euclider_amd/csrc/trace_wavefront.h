@@ -51,6 +51,41 @@
 #ifndef EU_SHADE_WAVES
 #define EU_SHADE_WAVES 3      /* waves per SIMD the shade kernel is compiled for (168 VGPRs) */
 #endif
+/* Work is DEALT, not divided: every launch gives each wave (intersect) or workgroup (shade) a first, static share and hands out the
+ * rest through counters in device memory, in units of one 64-ray batch / one shade window.  With static shares alone the slowest
+ * workgroup of a 1080p launch ran 1.5-1.9 times the mean (a few batches per wave, glass rays costing five times a wall ray's
+ * instructions) while the rest of the chip idled: profiles/r04_wg_profile_*.txt. */
+#ifndef EU_WF_DEAL_ISECT
+#define EU_WF_DEAL_ISECT 0      /* intersect kernel: batches beyond the static share are dealt through counters */
+#endif
+#ifndef EU_WF_DEAL_SHADE
+#define EU_WF_DEAL_SHADE 0      /* shade kernel: windows beyond each workgroup's first are dealt through a counter */
+#endif
+#ifndef EU_WF_STATIC_PCT
+#define EU_WF_STATIC_PCT 50   /* intersect: the share of a generation's batches dealt round-robin without asking a counter */
+#endif
+#ifndef EU_WF_WIN_MIN
+#define EU_WF_WIN_MIN 512u
+#endif
+#ifndef EU_WF_EQUAL_WIN
+#define EU_WF_EQUAL_WIN 1
+#endif
+#ifndef EU_SHADE_TAKE_CHUNKS
+#define EU_SHADE_TAKE_CHUNKS 1
+#endif
+#ifndef EU_WF_SPREAD
+#define EU_WF_SPREAD 1u       /* a shade window is made of this many pieces from equally spaced places of the generation's queue */
+#endif
+#ifndef EU_WF_DEAL_FACTOR
+#define EU_WF_DEAL_FACTOR 4u
+#endif
+#define EU_WORK_STRIDE 32u                       /* words between two work counters: each on a 128-byte line of its own (same-address atomics drain at ~88 per microsecond) */
+#ifndef EU_WORK_SHARDS
+#define EU_WORK_SHARDS 64u                       /* intersect: the dealt batches form this many interleaved classes with a counter each (a power of two).  512 waves on one
+                                                  * counter, a claim per ~6 us batch each, is the ~88 claims per microsecond at which one word saturates: with 8 classes the
+                                                  * claims' latency grew beyond the batch that was to hide it */
+#endif
+#define EU_WORK_PER_GEN ((EU_WORK_SHARDS + 1u) * EU_WORK_STRIDE)   /* + the shade kernel's window counter */
 
 #if defined(EU_PROFILE_SHADE_WAVE)      /* diagnostic build: wave-level shares of the shade kernel (LDS rows, first active lane: trace_device.h SHP): STAMP(k) closes
                                          * section k-1 (STAMP(0): what lies between two batches -> 15), SUB(k) closes sub-section k; sections do not overlap */
@@ -82,9 +117,24 @@ struct EuWfBuffers {
     EuTsNode *nodes;            /* [node_cap] */
     uint8_t *node_kind;         /* [node_cap] TS_NONE / TS_OVER / ...: what resolve has to do for the ray in this slot */
     uint32_t *seg_count;        /* [EU_MAX_DEPTH + 1][n_seg] rays in each segment of each generation's queue */
-    uint32_t ray_cap, node_cap, npix, pad;
+    uint32_t ray_cap, node_cap, npix, pad;      /* pad: the band pipeline's number (diagnostics) */
     uint32_t n_seg, seg_cap;    /* ray_cap = n_seg * seg_cap; node id of queue slot q of generation g = g * ray_cap + q */
+    uint32_t *work;             /* [EU_MAX_DEPTH + 1][EU_WORK_PER_GEN] work counters of this band pipeline, zeroed before every frame */
+    unsigned long long *prof;   /* diagnostics (-DEU_PROFILE_WG): [0] = records written, then 4 words per workgroup and launch; else NULL */
 };
+
+/* -DEU_PROFILE_WG: every workgroup of every launch leaves {kind | gen << 8 | band << 16 | block << 32, start, end, XCC | CU ids} (100 MHz clock):
+ * tools/wg_profile.py turns them into the share of the chip a launch keeps busy (tails, imbalance). */
+#ifdef EU_PROFILE_WG
+#define EU_PROF_CAP (1u << 20)
+#define WF_PROF_BEGIN() const unsigned long long wf_prof_t0 = wall_clock64()
+#define WF_PROF_END(B_, kind_, gen_) do { if (threadIdx.x == 0 && (B_).prof) { const unsigned long long i_ = atomicAdd((B_).prof, 1ull); if (i_ < EU_PROF_CAP) { \
+    unsigned long long *r_ = (B_).prof + 4 + 4 * i_; r_[0] = (unsigned long long)(kind_) | ((unsigned long long)(gen_) << 8) | ((unsigned long long)((B_).pad & 0xffu) << 16) | ((unsigned long long)blockIdx.x << 32); \
+    r_[1] = wf_prof_t0; r_[2] = wall_clock64(); r_[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)gridDim.x << 32); } } } while (0)
+#else
+#define WF_PROF_BEGIN() do { } while (0)
+#define WF_PROF_END(B_, kind_, gen_) do { } while (0)
+#endif
 
 EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) {
     /* one atomic per counter and WORKGROUP: same-address atomics drain at ~90 per microsecond, a per-wave flush of a
@@ -97,7 +147,7 @@ EU_DEV void wf_flush_counters(EuDevCounters *counters, const LaneCounters &cnt) 
         v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (v3 >> 30) atomicAdd(&counters->overflow, v3 >> 30);      /* lanes whose hit stack was full (EU_CNT_HS_FULL): the frame is traced again */
+        if (v3 >> 30) atomicAdd(&counters->hs_full, v3 >> 30);      /* lanes whose hit stack was full (EU_CNT_HS_FULL): the frame is traced again */
         v3 &= 0x3fffffffull;
         if (v0) atomicAdd(&wg_cnt[0], v0);
         if (v1) atomicAdd(&wg_cnt[1], v1);
@@ -166,6 +216,60 @@ EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_
     return lo * seg_cap + (v - pref[lo]);
 }
 
+/* ------------------------------------------------------------------ dealing 64-ray batches to waves (intersect kernel)
+ * Batch c covers rays [64 c, 64 c + 64) of the generation.  The first `s_end` batches are dealt round-robin (wave w takes w,
+ * w + n_waves, ...: no counter involved); a wave that has finished its static share claims the others one at a time (one claim is
+ * always in flight while a batch is traced, so its latency is hidden).  Any partition of the rays gives the same frame. */
+#define EU_WF_NO_BATCH 0xffffffffu
+struct WfDeal {
+    uint32_t n_waves, s_end, c_static, n_dyn, shard, len, pending;
+    uint32_t *ctr;
+    bool has_pending;
+    EU_DEV void init(uint32_t n_batches, uint32_t *work_gen) {
+        const uint32_t wave = blockIdx.x * (EU_WF_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        n_waves = gridDim.x * (EU_WF_BLOCK / 64);
+        s_end = n_batches;
+#if EU_WF_DEAL_ISECT
+        if (n_batches > n_waves) {
+            uint32_t per = (n_batches / n_waves) * EU_WF_STATIC_PCT / 100u;
+            if (per < 1u) per = 1u;
+            s_end = per * n_waves;
+        }
+#endif
+        c_static = wave;
+        n_dyn = n_batches - s_end;
+        /* the dealt batches are cut into EU_WORK_SHARDS interleaved classes (batch s_end + 8 j + x belongs to class x), each behind a
+         * counter on a cache line of its own, and a workgroup draws from class blockIdx % 8 only: neighbouring workgroups (dealt
+         * round-robin over the XCDs) use different counters, every class samples the whole generation, and a wave whose class is
+         * used up is done -- no wave ever goes looking for another counter (when that was allowed, all 4096 waves of a launch ended
+         * it by queueing on the same last counter: 40 us of same-address atomics per launch). */
+        shard = blockIdx.x & (EU_WORK_SHARDS - 1u);
+        len = n_dyn > shard ? (n_dyn - shard + EU_WORK_SHARDS - 1u) / EU_WORK_SHARDS : 0u;
+        ctr = work_gen + shard * EU_WORK_STRIDE;
+        has_pending = false; pending = 0;
+    }
+    EU_DEV uint32_t claim() const {      /* (every lane returns lane 0's ticket) */
+        uint32_t j = 0;
+        if ((threadIdx.x & 63u) == 0) j = atomicAdd(ctr, 1u);
+        return j;
+    }
+    /* the next batch of this wave, or EU_WF_NO_BATCH; wave-uniform */
+    EU_DEV uint32_t next() {
+        if (c_static < s_end) { const uint32_t c = c_static; c_static += n_waves; return c; }
+#if EU_WF_DEAL_ISECT
+        if (len == 0) return EU_WF_NO_BATCH;
+        const uint32_t j = __builtin_amdgcn_readfirstlane(has_pending ? pending : claim());
+        if (j < len) {
+            pending = claim();      /* for the call after this one: answered while this batch is traced */
+            has_pending = true;
+            return s_end + j * EU_WORK_SHARDS + shard;
+        }
+        len = 0;
+#endif
+        return EU_WF_NO_BATCH;
+    }
+};
+
 /* ------------------------------------------------------------------ queue helpers */
 struct WfRay { uint32_t q; };
 
@@ -202,8 +306,13 @@ EU_DEV EuPrimary wf_primary_ray(const EuScene &S, const EuDevCamera &cam, const 
     } else {
         const uint32_t tile = item >> 6, within = item & 63u;   /* 8x8 pixel tiles: coherent waves */
         pr.px_x = (tile % fr.tiles_x) * 8 + (within & 7);
-        ry = fr.band_row0 + (tile / fr.tiles_x) * 8 + (within >> 3);
-        if (pr.px_x >= fr.width || ry >= fr.local_rows || ry >= fr.band_row0 + fr.band_rows) return pr;
+        if (fr.band_stride > 1) {      /* concurrent bands of one frame take 8-row groups in turn: equal shares of whatever the picture shows */
+            ry = ((tile / fr.tiles_x) * fr.band_stride + fr.band_row0) * 8 + (within >> 3);
+            if (pr.px_x >= fr.width || ry >= fr.local_rows) return pr;
+        } else {
+            ry = fr.band_row0 + (tile / fr.tiles_x) * 8 + (within >> 3);
+            if (pr.px_x >= fr.width || ry >= fr.local_rows || ry >= fr.band_row0 + fr.band_rows) return pr;
+        }
         pr.out_idx = ry * fr.width + pr.px_x;
         if (fr.strip_count > 1) {   /* interleaved 8-row strips: this rank owns strips s with s % count == index */
             const uint32_t gstrip = (ry >> 3) * fr.strip_count + fr.strip_index;
@@ -245,6 +354,7 @@ template <int D, int HSCAP /* 0: per-lane hit stack in LDS (capacity hs_cap); el
 EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen, const EuDevCamera &cam, const EuDevFrame &fr,
                               const EuWfBuffers &B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov, uint64_t *lds_dyn) {
     constexpr bool g0 = G0;
+    WF_PROF_BEGIN();
     EuScene S;
     S.init(scene_g);      /* wave-uniform addresses: the scene arrives through scalar loads */
     typename eu_conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
@@ -276,25 +386,32 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
     SHP(cnt, 8);      /* kernel prologue: scene header, queue prefix */
     const bool trace_any = !g0 || cam.max_depth != 0;      /* trace() with depth 0 goes straight to the background: generation 0 only marks the pixels */
     {
-        /* software pipeline: the next ray of this lane is located and its loads are issued before the current one is
-         * intersected (the kernel keeps 3 waves per SIMD: too few to hide an HBM round trip behind other waves) */
-        const uint32_t v_step = gridDim.x * blockDim.x;
-        uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+        /* software pipeline: the next batch of this wave is asked for, its rays are located and their loads issued before the current
+         * batch is intersected (the kernel keeps 3 waves per SIMD: too few to hide an HBM round trip behind other waves) */
+        const uint32_t lane = threadIdx.x & 63u;
+        WfDeal deal;
+        deal.init((total + 63u) >> 6, B.work + gen * EU_WORK_PER_GEN);
+        uint32_t c_next = deal.next();
         uint32_t i_next = 0;
         real o_next[D], d_next[D];
 #pragma unroll
         for (int k = 0; k < D; k++) { o_next[k] = R(0.0); d_next[k] = R(0.0); }
-        if (!g0 && v < total) {
-            i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v);
+        if (!g0 && c_next != EU_WF_NO_BATCH && c_next * 64u + lane < total) {
+            i_next = wf_map_index(pref, B.n_seg, B.seg_cap, c_next * 64u + lane);
             wf_load_ray<D>(B, in, i_next, o_next, d_next);
         }
-        for (; v < total; v += v_step) {
+        while (c_next != EU_WF_NO_BATCH) {
+            const uint32_t v = c_next * 64u + lane;
             uint32_t i = i_next;
             real o[D], d[D];
-            bool live = true;
+            bool live = v < total;      /* (the generation's last batch may be ragged) */
             uint32_t out_idx = 0;
+#if EU_ISECT_PREFETCH
+            c_next = deal.next();
+#endif
             if (g0) {
                 i = v;
+                if (live) {
                 const EuPrimary pr = wf_primary_ray<D, P>(S, cam, fr, cam_ent, v, o, d);
                 out_idx = pr.out_idx;
                 if (pr.status != EU_PR_RAY) {
@@ -306,12 +423,13 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
                     B.hit[i] = h;
                     live = false;
                 }
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < D; k++) { o[k] = o_next[k]; d[k] = d_next[k]; }
 #if EU_ISECT_PREFETCH
-                if (v + v_step < total) {
-                    i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+                if (c_next != EU_WF_NO_BATCH && c_next * 64u + lane < total) {
+                    i_next = wf_map_index(pref, B.n_seg, B.seg_cap, c_next * 64u + lane);
                     wf_load_ray<D>(B, in, i_next, o_next, d_next);
                 }
 #endif
@@ -354,8 +472,9 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
             if (g0 && hit_t_aov) hit_t_aov[out_idx] = have ? best_t : -R(1.0);
             }
 #if !EU_ISECT_PREFETCH
-            if (!g0 && v + v_step < total) {
-                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, v + v_step);
+            c_next = deal.next();
+            if (!g0 && c_next != EU_WF_NO_BATCH && c_next * 64u + lane < total) {
+                i_next = wf_map_index(pref, B.n_seg, B.seg_cap, c_next * 64u + lane);
                 wf_load_ray<D>(B, in, i_next, o_next, d_next);
             }
 #endif
@@ -363,6 +482,7 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
         }
     }
     wf_flush_counters(counters, cnt);
+    WF_PROF_END(B, 0, gen);
 }
 
 template <int D, int HSCAP>
@@ -386,6 +506,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                           const EuWfBuffers &B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb,
                           uint64_t *lds_dyn) {
     constexpr bool g0 = G0;
+    WF_PROF_BEGIN();
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
     __syncthreads();
@@ -426,27 +547,59 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
      * (Fresnel + Snell + rotation) ~2500, and unsorted they would share waves. */
     __shared__ uint32_t sorted[EU_WF_WIN];
     __shared__ uint32_t hist[EU_WF_KEYS], offs[EU_WF_KEYS];
-    __shared__ uint32_t n_sorted;
+    __shared__ uint32_t n_sorted, next_win, next_chunk;
     {
-        /* a generation too small to give every workgroup a full window is cut into smaller ones: a window's rays are
-         * shaded EU_WF_BLOCK at a time, so its latency (the kernel's critical path) shrinks with it */
-        uint32_t win = EU_WF_WIN;      /* halved while the launch would leave workgroups without a window, down to one batch */
-        while (win > EU_WF_BLOCK && total <= gridDim.x * (win / 2)) win >>= 1;
-        /* (Round 3 measured a dynamic deal of the windows through one counter per launch: equal at best -- 6211 vs 6219 Mray/s on 3d_room --
-         * and 12 % slower on 3d_hallways when every workgroup's first window came from the counter too: 768 workgroups asking one address
-         * at the same moment at the start of every launch.) */
-        const uint32_t stride = gridDim.x * win;
-        const uint32_t iters = (total + stride - 1) / stride;
-        for (uint32_t it = 0; it < iters; it++) {
-            const uint32_t wbase = it * stride + blockIdx.x * win;
+        /* the window: every workgroup gets the same number of equally large windows (multiples of one batch; the counting sort's
+         * arrays hold EU_WF_WIN rays) -- with windows of a fixed 2048 rays a generation of 1.1 M rays was 557 windows for 768 workgroups,
+         * a quarter of which had nothing to do while the others shaded 2048 rays each.  Where windows are dealt they are made
+         * smaller, EU_WF_DEAL_FACTOR per workgroup, down to EU_WF_WIN_MIN: the window is the unit in which the work is balanced */
+        uint32_t win;
+        {
+            const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
+#if EU_WF_DEAL_SHADE
+            uint32_t target = (per_wg + EU_WF_DEAL_FACTOR - 1) / EU_WF_DEAL_FACTOR;
+            if (target < EU_WF_WIN_MIN) target = EU_WF_WIN_MIN < per_wg ? EU_WF_WIN_MIN : per_wg;
+#else
+            const uint32_t target = per_wg;
+#endif
+            const uint32_t k = (target + EU_WF_WIN - 1) / EU_WF_WIN;      /* windows the target is cut into */
+            win = (((target + (k ? k : 1u) - 1) / (k ? k : 1u)) + EU_WF_BLOCK - 1) / EU_WF_BLOCK * EU_WF_BLOCK;
+            if (win < EU_WF_BLOCK) win = EU_WF_BLOCK;
+#if !EU_WF_EQUAL_WIN      /* A/B: rounds 1-3's rule -- EU_WF_WIN, halved while the launch would leave workgroups without a window */
+            win = EU_WF_WIN;
+            while (win > EU_WF_BLOCK && total <= gridDim.x * (win / 2)) win >>= 1;
+#endif
+        }
+        const uint32_t n_win = (total + win - 1) / win;
+#if EU_WF_SPREAD > 1
+        uint32_t piece = win;      /* (pieces are powers of two; a window that is none stays in one piece) */
+        if ((win & (win - 1u)) == 0u) piece = win / EU_WF_SPREAD >= EU_WF_BLOCK ? win / EU_WF_SPREAD : EU_WF_BLOCK;
+        const uint32_t pshift = (piece & (piece - 1u)) == 0u ? (uint32_t)__builtin_ctz(piece) : 0u;
+#endif
+#if EU_WF_DEAL_SHADE
+        const bool dealt = n_win > gridDim.x;
+        uint32_t *win_ctr = B.work + gen * EU_WORK_PER_GEN + EU_WORK_SHARDS * EU_WORK_STRIDE;
+#endif
+        for (uint32_t w = blockIdx.x; w < n_win;) {
+#if EU_WF_DEAL_SHADE
+            uint32_t ticket = 0;
+            if (dealt && threadIdx.x == 0) ticket = atomicAdd(win_ctr, 1u);
+#endif
             if (threadIdx.x < EU_WF_KEYS) hist[threadIdx.x] = 0;
             __syncthreads();
             uint32_t myq[EU_WF_WIN / EU_WF_BLOCK], mykey[EU_WF_WIN / EU_WF_BLOCK], myrank[EU_WF_WIN / EU_WF_BLOCK];
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
-                const uint32_t v = wbase + k * EU_WF_BLOCK + threadIdx.x;
+                /* window w = the w-th piece of each of `spread` equal parts of the generation: a workgroup's rays come from several places
+                 * (a producer's output is sorted by what its rays hit, so neighbouring rays cost alike), each piece still contiguous */
+                const uint32_t kb = k * EU_WF_BLOCK;
+#if EU_WF_SPREAD > 1      /* (a piece is a multiple of the block: every thread of slot k is in the same piece, and the address arithmetic is scalar) */
+                const uint32_t v = (piece == win ? w * win + kb : (((kb >> pshift) * n_win + w) << pshift) + (kb & (piece - 1u))) + threadIdx.x;
+#else
+                const uint32_t v = w * win + kb + threadIdx.x;
+#endif
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
-                if (v < wbase + win && v < total) {
+                if (kb < win && v < total) {
                     myq[k] = g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v);
                     const uint32_t he = B.hit[myq[k]].ent;
                     if (he == EU_WF_ENT_DEAD) B.node_kind[node_base + myq[k]] = (uint8_t)TS_NONE;      /* (generation 0 only) nothing to shade, nothing to resolve */
@@ -457,15 +610,32 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } n_sorted = run; }
+            if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } n_sorted = run; next_chunk = 0; }
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) if (mykey[k] != 0xffffffffu) sorted[offs[mykey[k]] + myrank[k]] = myq[k];
             __syncthreads();
             const uint32_t n_live = n_sorted;
-#pragma unroll 1
-            for (uint32_t sub = 0; sub * EU_WF_BLOCK < n_live; sub++) {
-            const uint32_t sidx = sub * EU_WF_BLOCK + threadIdx.x;
+            /* The sorted window is shaded in chunks of one wave's 64 rays, and the waves of the workgroup TAKE chunks (a counter in LDS)
+             * instead of owning every fourth one: a chunk of glass rays costs five times a chunk of wall rays, the sort puts them
+             * side by side, and the other three waves would wait for the unlucky one at the window's last barrier.
+             * (Round 4 also measured a software pipeline here -- the next sub-batch's hit / routing / ray records requested before the
+             * current one is shaded: 19 more VGPRs, no gain: 1.694 vs 1.685 ms on 3d_room; what the kernel waits for is not these loads.) */
+            const uint32_t n_chunks = (n_live + 63u) >> 6;
+#if !EU_SHADE_TAKE_CHUNKS
+            uint32_t own_chunk = threadIdx.x >> 6;
+#endif
+            for (;;) {
+#if EU_SHADE_TAKE_CHUNKS
+            uint32_t chunk = 0;
+            if ((threadIdx.x & 63u) == 0) chunk = atomicAdd(&next_chunk, 1u);
+            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+#else       /* A/B: wave j owns chunks j, j + 4, ... */
+            const uint32_t chunk = own_chunk;
+            own_chunk += EU_WF_BLOCK / 64;
+#endif
+            if (chunk >= n_chunks) break;
+            const uint32_t sidx = chunk * 64u + (threadIdx.x & 63u);
             const bool live = sidx < n_live;
             const uint32_t i = live ? sorted[sidx] : 0u;
             WF_STAMP(0);
@@ -576,7 +746,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                         ts_deliver(B.nodes, parent, sm, inter, cnt, rgba, point_rgb);
                     }
                 }
-                B.node_kind[nid] = (uint8_t)node_kind;
+                B.node_kind[nid] = (uint8_t)(node_kind == TS_COMBINE_TRANS ? TS_COMBINE_TRANS : TS_NONE);      /* (only a node with two children is left to the resolve pass: trace_nodes.h) */
             }
             /* children with no depth left (or plain misses) only sample the background
              * (universe/mod.rs:157,183): one code site for all of them */
@@ -605,13 +775,21 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                 else wf_store_ray<D>(B, outb, out_base + pos1, c_o[1], c_d[1], c_parent[1], c_ent[1] | (c_sm[1] << 16));
             }
             WF_STAMP(7);
-            }   /* sub */
+            }   /* chunks */
+#if EU_WF_DEAL_SHADE
+            if (threadIdx.x == 0) next_win = dealt ? gridDim.x + ticket : n_win;
             __syncthreads();     /* `sorted` is rewritten by the next window */
+            w = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_win);
+#else
+            __syncthreads();     /* `sorted` is rewritten by the next window */
+            w += gridDim.x;
+#endif
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
     wf_flush_counters(counters, cnt);
+    WF_PROF_END(B, 1, gen);
 }
 
 template <int D, bool SCENE_LDS>
@@ -637,6 +815,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kern
  * moment holds the other band pipeline's ray queues.  One workgroup per queue segment, without the prefix table: 26 us per launch instead
  * of 19; the launch is bound by its node traffic -- 64-byte records, 32-byte deliveries -- and wants the whole chip's worth of waves.) */
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, uint32_t total0, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
+    WF_PROF_BEGIN();
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t node_base = gen * B.ray_cap;
     const bool g0 = gen == 0;
@@ -645,17 +824,11 @@ __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen
     const uint32_t total = g0 ? total0 : wf_build_prefix(B.seg_count + gen * B.n_seg, B.n_seg, pref, wave_tot);
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         const uint32_t nid = node_base + (g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v));
-        const uint32_t kind = B.node_kind[nid];
-        if (kind == TS_NONE) continue;
-        const EuTsNode *N = B.nodes + nid;
-        Rgba res = {N->c1[0], N->c1[1], N->c1[2], N->c1[3]};
-        if (kind != TS_COMBINE_INTER) {
-            const Rgba over = blend_rgba(EU_BL_OVER, new_u8(N->spx), new_u8(N->c0px));
-            res = kind == TS_OVER ? over : combine_palette_color(res, over, N->ratio);
-        }
-        ts_deliver(B.nodes, N->parent, (N->meta >> 8) & 7u, res, cnt, rgba, point_rgb);
+        if (B.node_kind[nid] != (uint8_t)TS_COMBINE_TRANS) continue;
+        ts_finish_two(B.nodes, B.nodes + nid, cnt, rgba, point_rgb);
     }
     wf_flush_counters(counters, cnt);
+    WF_PROF_END(B, 2, gen);
 }
 
 #endif

@@ -102,15 +102,16 @@ class Environment:
     #               thread: frames use the interpreter kernels until the code object is ready), None = the library default
     #   kernel: None / "wavefront" / "stack";  streams, ray_factor, band_pixels: 0 = default;  shade_scene_global: test hook
     def configure(self, specialize=None, kernel=None, streams=0, ray_factor=0.0, band_pixels=0, cache_dir=None, shade_scene_global=False,
-                  jit_flags=None, flags=0):
+                  jit_flags=None, flags=0, band_grid_permille=0, split_pixels=0):
         if self._renderers:
             raise RuntimeError("configure() before the first renderer exists")
         self._opts = dict(specialize=specialize, kernel=kernel, streams=streams, ray_factor=ray_factor, band_pixels=band_pixels,
-                          cache_dir=cache_dir, shade_scene_global=shade_scene_global, jit_flags=jit_flags, flags=flags)
+                          cache_dir=cache_dir, shade_scene_global=shade_scene_global, jit_flags=jit_flags, flags=flags,
+                          band_grid_permille=band_grid_permille, split_pixels=split_pixels)
         return self
 
     def _renderer_opts(self):
-        o = dict(DEFAULT_RENDERER_OPTS)
+        o = {k: v for k, v in DEFAULT_RENDERER_OPTS.items() if k != "on_specialize"}
         o.update({k: v for k, v in getattr(self, "_opts", {}).items() if v not in (None, 0, 0.0, False)})
         spec = {None: _capi.EU_SPECIALIZE_AUTO, "auto": _capi.EU_SPECIALIZE_AUTO, "off": _capi.EU_SPECIALIZE_OFF, "sync": _capi.EU_SPECIALIZE_SYNC,
                 "async": _capi.EU_SPECIALIZE_ASYNC}[o.get("specialize")]
@@ -120,7 +121,7 @@ class Environment:
         return _capi.RendererOpts(C.sizeof(_capi.RendererOpts), kern, spec, int(o.get("streams") or 0), float(o.get("ray_factor") or 0.0),
                                   int(o.get("band_pixels") or 0), cache.encode() if cache else None,
                                   (_capi.EU_RENDERER_SHADE_SCENE_GLOBAL if o.get("shade_scene_global") else 0) | int(o.get("flags") or 0), 0,
-                                  flags.encode() if flags else None)
+                                  flags.encode() if flags else None, int(o.get("band_grid_permille") or 0), int(o.get("split_pixels") or 0))
 
     def renderer(self, device=0):
         if device not in self._renderers:
@@ -132,6 +133,12 @@ class Environment:
             if rc != _capi.EU_OK:
                 raise EuError(rc, err.value.decode())
             self._renderers[device] = out
+            # a process-wide default of "sync" may come with a check (tests: the specialised pass must not pass on the interpreter
+            # kernels a failed compilation falls back to); an Environment's own configure(specialize=...) is the caller's business
+            check = DEFAULT_RENDERER_OPTS.get("on_specialize")
+            if check is not None and opts.specialize == _capi.EU_SPECIALIZE_SYNC and getattr(self, "_opts", {}).get("specialize") is None \
+                    and opts.kernel != _capi.EU_KERNEL_STACK:
+                check(self, self.jit_info(device))
         return self._renderers[device]
 
     def jit_info(self, device=0):
@@ -306,7 +313,7 @@ class Environment:
         st = _capi.Stats()
         rc = self._L.eu_renderer_stats(self.renderer(device), C.byref(st))
         if rc != _capi.EU_OK:
-            raise EuError(rc)
+            raise EuError(rc, (self._L.eu_renderer_error(self.renderer(device)) or b"").decode())
         return {"rays": st.rays, "bg_samples": st.bg_samples, "nan_pixels": st.nan_pixels, "errors": st.errors}
 
     def kernel_ms(self, device=0):
@@ -323,6 +330,24 @@ class Environment:
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return n.value
+
+    def wg_profile(self, device=0, max_records=1 << 20):
+        """Diagnostics (jit_flags -DEU_PROFILE_WG): first call switches the recording on and returns None; later calls return an
+        (n, 4) uint64 array {kind | gen << 8 | block << 32, start, end, hw id | grid << 32} of the launches since the previous call."""
+        import numpy as np
+        r = self.renderer(device)
+        if not getattr(self, "_wg_prof_on", False):
+            rc = self._L.eu_renderer_debug_wg_profile(r, None, 0, None)
+            if rc != _capi.EU_OK:
+                raise EuError(rc)
+            self._wg_prof_on = True
+            return None
+        buf = np.zeros((max_records, 4), dtype=np.uint64)
+        n = C.c_size_t(0)
+        rc = self._L.eu_renderer_debug_wg_profile(r, buf.ctypes.data, max_records, C.byref(n))
+        if rc != _capi.EU_OK:
+            raise EuError(rc)
+        return buf[:n.value].copy()
 
     def kernel_ms_history(self, n, device=0):
         buf = (C.c_float * max(1, n))()

@@ -137,7 +137,7 @@ typedef struct {
     uint32_t struct_size;        /* sizeof(eu_renderer_opts) of the caller: the struct may grow */
     uint32_t kernel;             /* EU_KERNEL_* */
     uint32_t specialize;         /* EU_SPECIALIZE_* */
-    uint32_t streams;            /* band pipelines in flight per frame, 1..4 (0: 2 for scenes whose recursion branches, else 1) */
+    uint32_t streams;            /* band pipelines in flight per frame, 1..8 (0: the library's choice) */
     double ray_factor;           /* ray-queue slots per pixel and generation (0: 4.0); a frame that needs more is reported through
                                     EU_ERR_CAPACITY (asynchronous calls) or traced again by the stack kernel (eu_render, eu_render_multi) */
     uint64_t band_pixels;        /* pixels per wavefront pass (0: 4 Mi): larger frames are traced in bands of whole 8-row tiles */
@@ -147,6 +147,8 @@ typedef struct {
     uint32_t reserved;
     const char *jit_flags;       /* extra compiler flags for the specialised kernels, space-separated (tuning experiments, e.g.
                                     "-DEU_SHADE_WAVES=4"); part of the cache key; NULL: none */
+    uint32_t band_grid_permille; /* the share of a full-chip grid (in 1/1000) every band pipeline of a frame launches (0: chosen from `streams`) */
+    uint32_t split_pixels;       /* frames of at least this many pixels are cut into `streams` concurrent bands (0: 524288) */
 } eu_renderer_opts;
 
 typedef struct {
@@ -162,6 +164,8 @@ int eu_renderer_create(const eu_scene *, int device, eu_renderer **out, char *er
 int eu_renderer_create_opts(const eu_scene *, int device, const eu_renderer_opts *opts, eu_renderer **out, char *err, size_t errlen);
 void eu_renderer_destroy(eu_renderer *);
 int eu_renderer_jit_info(eu_renderer *, eu_jit_info *out);
+/* What the most recent failing call on this renderer had to say (valid until the next call on it; "" if nothing failed yet). */
+const char *eu_renderer_error(const eu_renderer *);
 /* The HIP source eu_renderer_create_opts(EU_SPECIALIZE_SYNC) would compile for this scene (no GPU needed): *source is allocated
  * with eu_alloc, NUL-terminated; free it with eu_free.  key (optional, >= 40 bytes): the cache key. */
 int eu_scene_jit_source(const eu_scene *, char **source, char *key);
@@ -191,6 +195,9 @@ int eu_renderer_retraces(eu_renderer *, uint64_t *count);
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
  * (refill, intersect, shade, return); all zero in the shipped build. */
 int eu_renderer_debug_phases(eu_renderer *, unsigned long long out[16]);
+/* Diagnostics (kernels built with -DEU_PROFILE_WG among jit_flags): per-workgroup time stamps of every launch.  First call (out NULL):
+ * recording on; later calls copy the records (4 words each) written since the previous call. */
+int eu_renderer_debug_wg_profile(eu_renderer *, unsigned long long *out, size_t max_records, size_t *n_records);
 /* Diagnostics: rays queued per generation by the most recent frame's first band (the last band pipeline of buffer set 0). */
 int eu_renderer_debug_generations(eu_renderer *, unsigned long long out[17]);
 

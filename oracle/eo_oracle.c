@@ -160,7 +160,12 @@ const char *eo_last_error(const eo_scene *s) { return s->err; }
  * by eo_render; the shipped oracle (the timed CPU baseline) is built without them. */
 #ifdef EO_USE_LIBM      /* variant build: the platform libm (what Rust's f64::acos etc. call) instead of eo_math.h -- measures how far
                          * a <= 1 ulp difference in the elementary functions moves the rendered bytes (tests/test_oracle_libm.py) */
+#ifdef EO_LOW_PRECISION      /* F = f32 with the platform libm: the f32 entry points -- what the reference's `low_precision` binary calls (F::acos with F = f32,
+                              * util.rs:712-722, surface.rs:225,280; Cargo.toml:18-20) */
+#define EO_FN(name) name##f
+#else
 #define EO_FN(name) name
+#endif
 #else
 #define EO_FN(name) eo_##name
 #endif

@@ -64,7 +64,7 @@ def dvec32(vals, n=4):
 
 _libs = {}
 VARIANTS = {"": "libeo_oracle.so", "flops": "libeo_oracle_flops.so", "libm": "libeo_oracle_libm.so", "f32": "libeo_oracle_f32.so",
-            "asan": "libeo_oracle_asan.so"}
+            "f32_libm": "libeo_oracle_f32_libm.so", "asan": "libeo_oracle_asan.so"}
 
 
 def build(force=False, variant=""):
@@ -81,8 +81,8 @@ def lib(variant=""):
         return _libs[variant]
     L = C.CDLL(build(variant=variant))
     _libs[variant] = L
-    real = C.c_float if variant == "f32" else C.c_double      # F of this build
-    CameraT = Camera32 if variant == "f32" else Camera
+    real = C.c_float if variant in ("f32", "f32_libm") else C.c_double      # F of this build
+    CameraT = Camera32 if variant in ("f32", "f32_libm") else Camera
     dp = C.POINTER(real)
     ip = C.POINTER(C.c_int)
     vp = C.c_void_p
@@ -236,9 +236,9 @@ class OracleScene:
     def __init__(self, text, texture_loader=None, random_seed=0, variant=""):
         self.variant = variant
         self.L = lib(variant)
-        self.Camera = Camera32 if variant == "f32" else Camera
-        self.dvec = dvec32 if variant == "f32" else dvec
-        self.real_np = "float32" if variant == "f32" else "float64"
+        self.Camera = Camera32 if variant in ("f32", "f32_libm") else Camera
+        self.dvec = dvec32 if variant in ("f32", "f32_libm") else dvec
+        self.real_np = "float32" if variant in ("f32", "f32_libm") else "float64"
         self.random_seed = random_seed
         self.texture_loader = texture_loader or default_texture_loader([os.getcwd()])
         try:

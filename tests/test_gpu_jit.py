@@ -77,6 +77,7 @@ def test_sequence_and_trace_screen_point_on_specialised_kernels(scene, depth):
     a.close()
     b = Parser().parse_file(path).configure(specialize="sync")
     b.camera.max_depth = depth
+    assert b.jit_info()["active"], "the specialised kernels did not build: this test would compare the interpreter with itself"
     with FrameSequence(b, (192, 108), slots=3) as seq:
         for _ in range(3):
             seq.submit((192, 108))

@@ -314,12 +314,22 @@ def test_queue_overflow_falls_back_to_the_stack_kernel():
     multi = b.render_multi((1920, 1080), [0, 0])          # eu_render_multi re-traces an overflowing device's strips the same way
     assert np.array_equal(multi.data, good.data) and multi.stats == good.stats
     from euclider_amd import FrameSequence
-    from euclider_amd.environment import EuError
-    with FrameSequence(b, (1920, 1080), slots=1) as seq:          # the asynchronous path cannot retry: it reports the overflow
+    before = b.retraces()
+    with FrameSequence(b, (1920, 1080), slots=2) as seq:          # round 4: a frame of a sequence that overflowed is traced again when it is collected
         seq.submit((1920, 1080))
-        with pytest.raises(EuError) as ei:
-            seq.next()
-        assert ei.value.code == _capi.EU_ERR_CAPACITY
+        seq.submit((1920, 1080))
+        for _ in range(2):
+            img = seq.next()
+            assert np.array_equal(img.data, good.data) and img.stats == good.stats
+    assert b.retraces() == before + 2
+    # the plainly asynchronous call cannot retry: eu_renderer_stats reports the overflow and says what it was
+    import torch
+    from euclider_amd.environment import EuError
+    rgba = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda:0")
+    b.render_device(b.frame(1920, 1080, time=0.0, rows=(0, 1080)), rgba.data_ptr(), None, torch.cuda.current_stream().cuda_stream, device=0)
+    with pytest.raises(EuError) as ei:
+        b.stats(device=0)
+    assert ei.value.code == _capi.EU_ERR_CAPACITY and "queue" in str(ei.value)
     b.close()
 
 
