@@ -71,6 +71,9 @@ def parse_args():
                     help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 8: measured "
                          "5 / 8 / 12 in flight = 8.5 / 8.9 / 8.8 Gray/s on config 2 with 8 hardware queues, 8.0 / 8.2 / 8.4 with the runtime's 4; "
                          "1 = one frame at a time on two band streams)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps between two synchronisations) is run this many times; value and ms_per_step are the MEDIAN region, "
+                         "config.timed_regions carries min / median / max")
     ap.add_argument("--abi-child", type=int, default=0,
                     help="internal: ONE process drives this many GPUs through the C ABI (eu_render_multi) on the 8K frame and prints a JSON object")
     return ap.parse_args()
@@ -148,6 +151,20 @@ def load_pmc(workload_key):
             return json.load(f).get(workload_key, {})
     except Exception:
         return {}
+
+
+_GOLDEN_FRAMES = None
+
+
+def golden_frames():
+    global _GOLDEN_FRAMES
+    if _GOLDEN_FRAMES is None:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "frame_sha.json")) as f:
+                _GOLDEN_FRAMES = json.load(f)
+        except Exception:
+            _GOLDEN_FRAMES = {}
+    return _GOLDEN_FRAMES
 
 
 def load_traffic(workload_key):
@@ -333,15 +350,38 @@ def other_configs(torch, dev, Parser, args, in_flight):
         dt = (time.perf_counter() - t0) / steps
         st = env.stats(device=dev.index)
         agree = all(torch.equal(rgb[0][:H * W * 3], x[:H * W * 3]) for x in rgb[1:])
+        # the frame this run left in HBM against the ORACLE's frame of the same workload, by checksum (tests/golden/frame_sha.json, made on the CPU
+        # by tools/make_frame_sha.py): the comparison costs no oracle time here
+        import hashlib
+        key = "%s %dx%d depth %d%s" % (scene, W, H, depth, " f32" if lp else "")
+        gold = golden_frames().get(key)
+        sha = hashlib.sha256(rgb[0][:H * W * 3].cpu().numpy().tobytes()).hexdigest()
+        vs_oracle = None if gold is None else {"frame_equal": sha == gold["sha256"], "rays_equal": int(st["rays"]) == gold["rays"], "bytes_compared": gold["bytes"]}
+        # one frame at a time on a renderer with the library's defaults (the reference's call shape)
+        ea = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
+        ea.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
+        ea.camera.max_depth = depth
+        raw = torch.cuda.current_stream(dev).cuda_stream
+        ts = []
+        for k in range(2 + (4 if W * H > (4 << 20) else 9)):
+            t1 = time.perf_counter()
+            ea.render_device(frame, rgba[0].data_ptr(), None, raw, device=dev.index)
+            ea.pack_rgb_device(rgba[0].data_ptr(), rgb[0].data_ptr(), H * W, raw, device=dev.index)
+            torch.cuda.synchronize(dev)
+            if k >= 2:
+                ts.append((time.perf_counter() - t1) * 1e3)
+        ts.sort()
+        ea.close()
         kernel_ms = dt * 1e3      # a frame's share of the device (frames overlap; see the headline's roofline)
         alg = 4.0 * W * H + 16.0 * st["bg_samples"] + env.info.flat_bytes
         ach = alg / (kernel_ms * 1e-3) / 1e9
         out.append({"workload": "%s %dx%d depth %d%s" % (scene, W, H, depth, ", low_precision (F = f32, its own rays and pixels)" if lp else ""),
                     "dtype": "f32" if lp else "f64", "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
-                    "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": R, "slots_agree": agree, "rays_per_frame": int(st["rays"]),
+                    "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": R, "slots_agree": agree, "vs_oracle": vs_oracle, "rays_per_frame": int(st["rays"]),
+                    "one_frame_alone": {"ms": ts[len(ts) // 2], "Mray/s": st["rays"] / ts[len(ts) // 2] / 1e3, "frames": len(ts)},
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
+                                 "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": None if lp else load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
                                  "flops": None if lp else flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)},
                     "specialized": env.jit_info(device=dev.index)["active"]})
         for e in envs:
@@ -389,9 +429,9 @@ def main():
     in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 8
     band_streams = args.streams or (1 if in_flight > 1 else 0)      # frames in flight fill each other's kernel tails; a lone frame is cut into two bands for that
 
-    def make_env():
+    def make_env(streams=None):
         e = Parser(low_precision=args.low_precision).parse_file(scene_path)
-        e.configure(specialize=args.specialize, streams=band_streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
+        e.configure(specialize=args.specialize, streams=band_streams if streams is None else streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
         e.camera.max_depth = args.max_depth
         return e
     env = make_env()
@@ -405,7 +445,7 @@ def main():
         animate(args, env, scene_path)
         env.close()
         return
-    def timed_run(W, H, steps, warmup, n_slots):
+    def timed_run(W, H, steps, warmup, n_slots, repeats=1):
         """K steps of the partitioned frame (this rank's strips traced, packed, gathered on rank 0, rows restored), timed
         between barriers + device synchronisation; returns max-over-ranks wall time and summed counters.  Step k uses slot k % n_slots:
         a renderer, a stream and buffers of its own, so that up to n_slots frames are in flight (the production frame loop,
@@ -469,38 +509,62 @@ def main():
 
         for k in range(max(warmup, n_slots)):      # (every slot's renderer sizes its buffers on its first frame)
             step(k)
-        sync()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            step(k)
-        sync()
-        elapsed = time.perf_counter() - t0
+        regions = []
+        rdev = torch.device("cpu") if smoke_gloo else dev
+        for _ in range(max(1, repeats)):           # the timed region, several times over: exactly `steps` steps between two synchronisations each
+            sync()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(k)
+            sync()
+            tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
+            if world > 1:
+                dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            regions.append(tr.item())
+        elapsed = sorted(regions)[len(regions) // 2]
         st = env.stats(device=local_rank)
-        # one frame alone (slot 0, nothing else in flight): the latency next to the pipelined throughput
-        t1 = time.perf_counter()
-        for _ in range(3):
-            step(0)
-            torch.cuda.synchronize(dev)
-        alone_ms = (time.perf_counter() - t1) / 3 * 1e3
         kms = env.kernel_ms_history(3, device=local_rank)
         same = True
         if rank == 0 and n_slots > 1:      # every slot rendered the same frame: their images must be identical
             same = all(torch.equal(slots[0]["rgb_out"][:H * W * 3], sl["rgb_out"][:H * W * 3]) for sl in slots[1:])
-        rdev = torch.device("cpu") if smoke_gloo else dev
         tot = torch.tensor([float(st["rays"]), float(st["bg_samples"]), float(st["nan_pixels"] + st["errors"])], dtype=torch.float64, device=rdev)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         if world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return {"W": W, "H": H, "elapsed": tmax.item(), "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
-                "local_rows": local_rows, "rgb_out": slots[0]["rgb_out"], "steps": steps, "alone_ms": alone_ms, "slots_agree": same}
+        return {"W": W, "H": H, "elapsed": elapsed, "regions": regions, "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
+                "local_rows": local_rows, "rgb_out": slots[0]["rgb_out"], "steps": steps, "slots_agree": same, "step": step, "sync": sync, "slots": slots}
 
     parity_failed = False
     W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
-    run = timed_run(W, H, args.steps, args.warmup, in_flight)
+    run = timed_run(W, H, args.steps, args.warmup, in_flight, args.repeats)
     elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
     tot = [run["rays"], 0.0, run["panic"]]
     stream = torch.cuda.current_stream(dev).cuda_stream
+
+    # ONE frame at a time -- the reference's call shape (Environment::render is synchronous: simulation.rs:86, universe/mod.rs:300-357): a
+    # renderer with the library's own defaults (its band pipelines on its own streams), launch + pack + wait, frame after frame
+    alone = None
+    if world == 1:
+        ea = make_env(streams=args.streams)
+        frame1 = ea.frame(W, H, time=0.0, rows=(0, H))
+        rgba1 = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        rgb1 = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
+        raw = torch.cuda.current_stream(dev).cuda_stream
+        ts = []
+        for k in range(3 + 15):
+            t1 = time.perf_counter()
+            ea.render_device(frame1, rgba1.data_ptr(), None, raw, device=local_rank)
+            ea.pack_rgb_device(rgba1.data_ptr(), rgb1.data_ptr(), H * W, raw, device=local_rank)
+            torch.cuda.synchronize(dev)
+            if k >= 3:
+                ts.append((time.perf_counter() - t1) * 1e3)
+        ts.sort()
+        akms = ea.kernel_ms_history(8, device=local_rank)
+        alone = {"ms": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "frames": len(ts), "Mray/s": rays_per_step / ts[len(ts) // 2] / 1e3,
+                 "kernel_ms": sum(akms) / max(1, len(akms)), "same_frame": bool(torch.equal(rgb1[:H * W * 3], rgb_out[:H * W * 3])),
+                 "band_streams": args.streams or "library default",
+                 "note": "launch, pack, wait -- repeat: one renderer with the library's defaults, nothing else in flight (host launch time and the final wait included; kernel_ms = HIP events around the frame's pipeline)"}
+        ea.close()
+        del rgba1, rgb1
 
     cfg5 = cfg5_abi = None
     if world > 1 and not args.fixed_frame:      # BASELINE config 5 next to the weak-scaling value: the 8K frame over the same ranks (strong scaling)
@@ -527,8 +591,7 @@ def main():
         value = rays_per_step * args.steps / elapsed / 1e6
         # device time per frame: with frames in flight the pipelines overlap, so a frame's share of the device is the timed region / steps (HIP
         # events bracket it: torch.cuda.synchronize on both sides); `frame_alone_kernel_ms` is the HIP-event span of one frame's pipeline on its own
-        alone_kernel_ms = sum(kms) / max(1, len(kms))
-        kernel_ms = elapsed / args.steps * 1e3 if in_flight > 1 else alone_kernel_ms
+        kernel_ms = elapsed / args.steps * 1e3 if in_flight > 1 else sum(kms) / max(1, len(kms))
         # algorithmic bytes of ONE launch of the trace kernel on this rank (DESIGN.md "Roofline"):
         # 4 B RGBA8 store per pixel + 16 B (4 RGBA8 texels) per background sample + the flat scene once
         alg_bytes = 4.0 * local_rows * W + 16.0 * st["bg_samples"] + env.info.flat_bytes
@@ -543,8 +606,9 @@ def main():
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
                        "frames_in_flight": in_flight, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "band_streams_per_frame": band_streams or "library default (2 for this scene)",
-                       "one_frame_alone": {"ms": run["alone_ms"], "Mray/s": rays_per_step / run["alone_ms"] / 1e3, "kernel_ms": alone_kernel_ms,
-                                           "note": "the same renderer with nothing else in flight (latency of one frame)"},
+                       "one_frame_alone": alone,
+                       "timed_regions": {"repeats": len(run["regions"]), "ms_per_step_min": min(run["regions"]) / args.steps * 1e3,
+                                         "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": max(run["regions"]) / args.steps * 1e3},
                        "slots_agree": run["slots_agree"],
                        "kernels": ("specialised for the scene at renderer creation (hiprtc%s, %.0f ms)" % (", code object from the cache" if jit["from_cache"] else "", jit["compile_ms"])) if jit["active"] else "ahead-of-time, interpreting the flat scene",
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",

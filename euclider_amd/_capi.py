@@ -70,6 +70,7 @@ class JitInfo(C.Structure):
 EU_KERNEL_AUTO, EU_KERNEL_WAVEFRONT, EU_KERNEL_STACK = 0, 1, 2
 EU_SPECIALIZE_AUTO, EU_SPECIALIZE_OFF, EU_SPECIALIZE_SYNC, EU_SPECIALIZE_ASYNC = 0, 1, 2, 3
 EU_RENDERER_SHADE_SCENE_GLOBAL = 1
+EU_RENDERER_NO_FUSE = 2
 
 TEXTURE_LOADER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                              C.POINTER(C.c_void_p))

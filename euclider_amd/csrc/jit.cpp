@@ -25,7 +25,7 @@
 
 namespace euclider {
 
-#define EU_JIT_VERSION "eu-jit-3"
+#define EU_JIT_VERSION "eu-jit-4"
 
 /* the device headers, embedded at build time (csrc/Makefile: jit_headers.inc) */
 struct EmbeddedHeader { const char *name; const char *text; };
@@ -520,8 +520,9 @@ static std::string hex_digest(const std::string &a, const std::string &b) {
 
 }  // namespace
 
-JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
+JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags, bool fused) {
     JitPlan plan;
+    plan.fused = fused;
     {
         size_t i = 0;
         while (i < extra_flags.size()) {
@@ -548,20 +549,34 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
     g.generate();
     Out tail;
     const unsigned hscap = plan.hs_lds ? 0u : plan.hs_cap;
-    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen,\n"
-           "        EuWfBuffers B, EuDevCounters *counters) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
-           "    wf_intersect_body<%d, %u, EuJit, false>(scene_g, hs_cap, gen, cam, fr, B, counters, nullptr, lds_dyn);\n}\n\n", plan.dim, hscap);
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect0(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,\n"
            "        EuWfBuffers B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov) {\n    extern __shared__ uint64_t lds_dyn[];\n"
            "    wf_intersect_body<%d, %u, EuJit, true>(scene_g, hs_cap, 0u, cam, fr, B, counters, hit_t_aov, lds_dyn);\n}\n\n", plan.dim, hscap);
+    if (!fused) {
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, uint32_t gen,\n"
+           "        EuWfBuffers B, EuDevCounters *counters) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
+           "    wf_intersect_body<%d, %u, EuJit, false>(scene_g, hs_cap, gen, cam, fr, B, counters, nullptr, lds_dyn);\n}\n\n", plan.dim, hscap);
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_shade(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, real time_s,\n"
            "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
            "    wf_shade_body<%d, false, EuJit, false>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn);\n}\n\n", plan.dim);
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_shade0(const uint64_t *__restrict__ scene_g, uint32_t scene_words, EuDevCamera cam, EuDevFrame fr,\n"
            "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n"
            "    wf_shade_body<%d, false, EuJit, true>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn);\n}\n", plan.dim);
+    } else {
+    /* the fused forms: shade generation g, then intersect the rays just queued (trace_wavefront.h: FUSE) */
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_fshade(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t max_depth, real time_s,\n"
+           "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
+           "    wf_shade_body<%d, false, EuJit, false, %u>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn, hs_cap);\n}\n\n", plan.dim, hscap);
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_fshade0(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,\n"
+           "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n"
+           "    wf_shade_body<%d, false, EuJit, true, %u>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn, hs_cap);\n}\n", plan.dim, hscap);
+    }
     plan.source = g.o.s + tail.s;
     std::string dep = EU_JIT_VERSION;
+    {   /* a code object is only as good as the compiler that made it: the hiprtc version is part of the key */
+        int major = 0, minor = 0;
+        if (hiprtcVersion(&major, &minor) == HIPRTC_SUCCESS) dep += " hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+    }
     for (const char *f : kCompileFlags) { dep += ' '; dep += f; }
     for (const std::string &f : plan.extra_flags) { dep += ' '; dep += f; }
     for (int k = 0; k < kNumHeaders; k++) { dep += kHeaders[k].name; dep += kHeaders[k].text; }
@@ -572,6 +587,12 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags) {
 /* ------------------------------------------------------------------ build + cache */
 static std::mutex g_mem_mutex;
 static std::map<std::string, std::vector<char>> g_mem_cache;      /* key -> code object (a process often creates several renderers of one scene) */
+static std::deque<std::string> g_mem_order;                       /* oldest first: a long-lived process that loads scene after scene keeps the last 64 */
+static void mem_cache_put(const std::string &fname, const std::vector<char> &code) {      /* (g_mem_mutex held) */
+    if (g_mem_cache.find(fname) == g_mem_cache.end()) g_mem_order.push_back(fname);
+    g_mem_cache[fname] = code;
+    while (g_mem_order.size() > 64) { g_mem_cache.erase(g_mem_order.front()); g_mem_order.pop_front(); }
+}
 
 static bool read_file(const std::string &path, std::vector<char> &out) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -589,15 +610,23 @@ static bool read_file(const std::string &path, std::vector<char> &out) {
 static void mkdirs(const std::string &dir) {
     std::string cur;
     for (size_t i = 0; i <= dir.size(); i++) {
-        if (i == dir.size() || dir[i] == '/') { if (!cur.empty()) (void)mkdir(cur.c_str(), 0755); }
+        if (i == dir.size() || dir[i] == '/') { if (!cur.empty()) (void)mkdir(cur.c_str(), i == dir.size() ? 0700 : 0755); }
         if (i < dir.size()) cur += dir[i];
     }
 }
 
-static std::string default_cache_dir() {
+/* Code objects run on the GPU as they are found: a cache directory is only read or written if it belongs to this user and nobody else
+ * can write to it (a world-writable directory would let another local user plant <key>.hsaco). */
+static bool dir_is_private(const std::string &dir) {
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
+static std::string default_cache_dir() {      /* "": no private place to keep code objects -- they then live in memory only */
     if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/euclider_amd";
     if (const char *hm = getenv("HOME")) if (*hm) return std::string(hm) + "/.cache/euclider_amd";
-    return "/tmp/euclider_amd_cache";
+    return std::string();
 }
 
 static std::string library_cache_dir() {      /* <directory of this shared library>/jit_cache */
@@ -628,12 +657,14 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
     }
     const std::string user_dir = cache_dir_in.empty() ? default_cache_dir() : cache_dir_in;
     const std::string lib_dir = library_cache_dir();
-    for (const std::string &dir : {lib_dir, user_dir}) {
+    for (int which = 0; which < 2; which++) {
+        const std::string &dir = which == 0 ? lib_dir : user_dir;
         if (dir.empty()) continue;
+        if (which == 1 && !dir_is_private(dir)) continue;      /* (the directory next to the library is as trustworthy as the library) */
         if (read_file(dir + "/" + fname, out.code)) {
             out.from_cache = true;
             std::lock_guard<std::mutex> lk(g_mem_mutex);
-            g_mem_cache[fname] = out.code;
+            mem_cache_put(fname, out.code);
             return EU_OK;
         }
     }
@@ -664,8 +695,9 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
     if (rc != HIPRTC_SUCCESS || code_size == 0) { out.log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
     out.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out.from_cache = false;
-    {   /* keep it: atomically, so that a concurrent reader never sees half a file */
+    if (!user_dir.empty()) {   /* keep it: atomically, so that a concurrent reader never sees half a file */
         mkdirs(user_dir);
+        if (!dir_is_private(user_dir)) { std::lock_guard<std::mutex> lk(g_mem_mutex); mem_cache_put(fname, out.code); return EU_OK; }
         char tmpn[64];
         snprintf(tmpn, sizeof tmpn, ".tmp.%ld.%p", (long)getpid(), (void *)&out);
         const std::string tmp = user_dir + "/" + fname + tmpn, fin = user_dir + "/" + fname;
@@ -677,8 +709,24 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
         }
     }
     std::lock_guard<std::mutex> lk(g_mem_mutex);
-    g_mem_cache[fname] = out.code;
+    mem_cache_put(fname, out.code);
     return EU_OK;
+}
+
+/* a cached code object that the runtime refused to load: forget it (memory and the user's directory), so that the next jit_build compiles */
+void jit_forget(const JitPlan &plan, const std::string &cache_dir_in) {
+#if EU_REAL_BITS == 32
+    const std::string fname = plan.key + "_f32.hsaco";
+#else
+    const std::string fname = plan.key + ".hsaco";
+#endif
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        g_mem_cache.erase(fname);
+        for (auto it = g_mem_order.begin(); it != g_mem_order.end(); ++it) if (*it == fname) { g_mem_order.erase(it); break; }
+    }
+    const std::string user_dir = cache_dir_in.empty() ? default_cache_dir() : cache_dir_in;
+    if (!user_dir.empty() && dir_is_private(user_dir)) (void)unlink((user_dir + "/" + fname).c_str());
 }
 
 /* ------------------------------------------------------------------ asynchronous compilation (EU_SPECIALIZE_ASYNC) */
@@ -687,6 +735,7 @@ struct JitWorker {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::shared_ptr<JitJob>> queue;
+    std::vector<std::weak_ptr<JitJob>> inflight;      /* queued or compiling, for jit_submit to join */
     std::thread thread;
     bool stop = false, started = false;
     void run() {
@@ -699,8 +748,8 @@ struct JitWorker {
                 job = queue.front();
                 queue.pop_front();
             }
-            if (job->cancelled.load()) { job->rc = EU_ERR_BUSY; job->done.store(true, std::memory_order_release); continue; }
-            job->plan = jit_generate(*job->flat, job->flags);
+            if (job->waiters.load() <= 0) { job->rc = EU_ERR_BUSY; job->done.store(true, std::memory_order_release); continue; }
+            job->plan = jit_generate(*job->flat, job->flags, job->fused);
             job->rc = jit_build(job->plan, job->cache_dir, job->build);
             job->done.store(true, std::memory_order_release);
         }
@@ -718,14 +767,24 @@ struct JitWorker {
 JitWorker &worker() { static JitWorker w; return w; }
 }  // namespace
 
-std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags) {
-    auto job = std::make_shared<JitJob>();
-    job->flat = std::move(flat); job->cache_dir = cache_dir; job->flags = flags;
+std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags, const std::string &key, bool fused) {
     JitWorker &w = worker();
+    std::shared_ptr<JitJob> job;
     {
         std::lock_guard<std::mutex> lk(w.mu);
+        /* the same scene, flags and cache directory already queued or compiling (the slots of a frame sequence, one renderer per device): join it */
+        for (auto it = w.inflight.begin(); it != w.inflight.end();) {
+            std::shared_ptr<JitJob> j = it->lock();
+            if (!j || j->done.load(std::memory_order_acquire)) { it = w.inflight.erase(it); continue; }
+            if (j->key == key && j->cache_dir == cache_dir) { j->waiters.fetch_add(1); return j; }
+            ++it;
+        }
+        job = std::make_shared<JitJob>();
+        job->flat = std::move(flat); job->cache_dir = cache_dir; job->flags = flags; job->key = key; job->fused = fused;
+        job->waiters.store(1);
         if (!w.started) { w.thread = std::thread([&w] { w.run(); }); w.started = true; }
         w.queue.push_back(job);
+        w.inflight.push_back(job);
     }
     w.cv.notify_one();
     return job;

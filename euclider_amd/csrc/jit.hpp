@@ -29,6 +29,8 @@ struct JitPlan {
     std::string source;          /* HIP source of the translation unit */
     std::vector<std::string> extra_flags;      /* caller's tuning flags (eu_renderer_opts.jit_flags), part of the key */
     std::string key;             /* hex digest of everything the code object depends on */
+    bool fused = true;           /* the module holds the fused kernels (intersect0, fshade0, fshade: one launch per generation) or the two-kernel pipeline's
+                                  * (intersect0, intersect, shade0, shade: eu_renderer_opts.flags & EU_RENDERER_NO_FUSE) */
     bool too_large = false;      /* the scene has more shape ops / entities than straight-line code is worth compiling for (jit_build refuses) */
 };
 
@@ -38,7 +40,7 @@ struct JitPlan {
 constexpr uint32_t kJitMaxShapeOps = 256, kJitMaxEntities = 48;
 
 /* Pure host code (no HIP call): the specialised translation unit for this scene. */
-JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags = std::string());
+JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags = std::string(), bool fused = true);
 
 struct JitBuild {
     std::vector<char> code;      /* gfx950 code object */
@@ -51,6 +53,8 @@ struct JitBuild {
  * (read / write; empty: $XDG_CACHE_HOME/euclider_amd or ~/.cache/euclider_amd) and the read-only directory `jit_cache` next
  * to the library (kernels compiled at build time travel with it).  Returns 0 or a negative EU_ERR_* code (log says why). */
 int jit_build(const JitPlan &plan, const std::string &cache_dir, JitBuild &out, bool cache_only = false);
+/* A cached code object the runtime would not load (a truncated or foreign file): dropped from memory and from the user's cache directory. */
+void jit_forget(const JitPlan &plan, const std::string &cache_dir);
 
 /* EU_SPECIALIZE_ASYNC: the compilation runs on a worker thread of this library (one for the process: jobs are served in order) while the
  * renderer traces with the interpreter kernels; the renderer polls `done` when a frame is launched.  A job whose renderer is gone before
@@ -59,12 +63,15 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir, JitBuild &out, 
 struct JitJob {
     std::shared_ptr<const FlatScene> flat;
     std::string cache_dir, flags;
+    bool fused = true;
     JitPlan plan;
     JitBuild build;
     int rc = 0;
-    std::atomic<bool> done{false}, cancelled{false};
+    std::string key;             /* the plan's key: renderers of the same scene (sequence slots, one per device) share ONE job */
+    std::atomic<bool> done{false};
+    std::atomic<int> waiters{0};  /* renderers that still want the result */
 };
-std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags);
+std::shared_ptr<JitJob> jit_submit(std::shared_ptr<const FlatScene> flat, const std::string &cache_dir, const std::string &flags, const std::string &key, bool fused);
 
 }  // namespace euclider
 

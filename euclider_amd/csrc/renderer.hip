@@ -50,7 +50,7 @@ __global__ void eu_pack_rgb_kernel(const uint32_t *__restrict__ rgba, uint8_t *_
 __global__ void eu_wf_clear_kernel(EuDevCounters *counters, uint32_t *work, uint32_t words_per_band, uint32_t n_bands, uint32_t n_gen) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (uint32_t i = t; i < sizeof(EuDevCounters) / 8; i += nt) ((unsigned long long *)counters)[i] = 0ull;
-    const uint32_t per_gen = EU_WORK_SHARDS + 1u, per_band = n_gen * per_gen;
+    const uint32_t per_gen = EU_WORK_SLOTS, per_band = n_gen * per_gen;
     for (uint32_t i = t; i < n_bands * per_band; i += nt) {
         const uint32_t band = i / per_band, r = i % per_band;
         work[(size_t)band * words_per_band + (size_t)(r / per_gen) * EU_WORK_PER_GEN + (size_t)(r % per_gen) * EU_WORK_STRIDE] = 0u;
@@ -108,6 +108,8 @@ struct eu_renderer {
     /* scene-specialised kernels (jit.hpp), when the renderer was created with EU_SPECIALIZE_SYNC and the compilation succeeded */
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_intersect = nullptr, jit_shade = nullptr, jit_intersect0 = nullptr, jit_shade0 = nullptr;      /* ...0: generation 0 */
+    hipFunction_t jit_fshade = nullptr, jit_fshade0 = nullptr;      /* the fused forms: shade, then intersect the rays just queued */
+    bool fuse = true;                        /* a generation is ONE launch (fused shade + intersect) where such kernels exist (eu_renderer_opts.flags: EU_RENDERER_NO_FUSE) */
     bool jit_hs_lds = true;
     uint32_t jit_hs_cap = 0;
     eu_jit_info jit = {};
@@ -170,25 +172,36 @@ static void fill_jit_info(const euclider::JitPlan &plan, const euclider::JitBuil
 static void renderer_load_jit(eu_renderer *r, const euclider::JitPlan &plan, const euclider::JitBuild &b) {
     fill_jit_info(plan, b, false, r->jit);
     if (hipModuleLoadData(&r->jit_module, b.code.data()) != hipSuccess) { (void)hipGetLastError(); r->jit_module = nullptr; r->jit_log += "\nhipModuleLoadData failed"; return; }
-    if (hipModuleGetFunction(&r->jit_intersect, r->jit_module, "eu_jit_intersect") != hipSuccess ||
-        hipModuleGetFunction(&r->jit_shade, r->jit_module, "eu_jit_shade") != hipSuccess ||
-        hipModuleGetFunction(&r->jit_intersect0, r->jit_module, "eu_jit_intersect0") != hipSuccess ||
-        hipModuleGetFunction(&r->jit_shade0, r->jit_module, "eu_jit_shade0") != hipSuccess) {
+    bool ok = hipModuleGetFunction(&r->jit_intersect0, r->jit_module, "eu_jit_intersect0") == hipSuccess;
+    if (plan.fused) ok = ok && hipModuleGetFunction(&r->jit_fshade, r->jit_module, "eu_jit_fshade") == hipSuccess &&
+                         hipModuleGetFunction(&r->jit_fshade0, r->jit_module, "eu_jit_fshade0") == hipSuccess;
+    else ok = ok && hipModuleGetFunction(&r->jit_intersect, r->jit_module, "eu_jit_intersect") == hipSuccess &&
+              hipModuleGetFunction(&r->jit_shade, r->jit_module, "eu_jit_shade") == hipSuccess &&
+              hipModuleGetFunction(&r->jit_shade0, r->jit_module, "eu_jit_shade0") == hipSuccess;
+    if (!ok) {
         (void)hipGetLastError();
         (void)hipModuleUnload(r->jit_module);
-        r->jit_module = nullptr; r->jit_intersect = nullptr; r->jit_shade = nullptr; r->jit_intersect0 = nullptr; r->jit_shade0 = nullptr;
+        r->jit_module = nullptr; r->jit_intersect = nullptr; r->jit_shade = nullptr; r->jit_intersect0 = nullptr; r->jit_shade0 = nullptr; r->jit_fshade = nullptr; r->jit_fshade0 = nullptr;
         r->jit_log += "\nthe code object lacks the kernels";
         return;
     }
     r->jit_hs_lds = plan.hs_lds;
     r->jit_hs_cap = plan.hs_cap;
     r->jit.active = 1;
+    /* producer workgroups per CU = what the producer kernels' registers and LDS allow.  (A renderer that switches kernels between two
+     * frames -- EU_SPECIALIZE_ASYNC -- keeps its buffers: wf_launch_frame uses at most the segments they were cut into.) */
+    const bool fused = r->jit_fshade != nullptr;
+    const size_t dyn = fused && plan.hs_lds ? (size_t)(EU_WF_BLOCK / 64) * plan.hs_cap * 64 * (sizeof(real) + 4) : 0;
+    if (dyn > 64 * 1024) {      /* beyond the default limit of dynamic LDS per workgroup */
+        (void)hipFuncSetAttribute((const void *)r->jit_fshade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute((const void *)r->jit_fshade0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipGetLastError();
+    }
     int occ = 0, occ0 = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, r->jit_shade, EU_WF_BLOCK, 0) == hipSuccess &&
-        hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, r->jit_shade0, EU_WF_BLOCK, 0) == hipSuccess) {
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fused ? r->jit_fshade : r->jit_shade, EU_WF_BLOCK, dyn) == hipSuccess &&
+        hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, fused ? r->jit_fshade0 : r->jit_shade0, EU_WF_BLOCK, dyn) == hipSuccess) {
         const int o = occ < occ0 ? occ : occ0;
-        const uint32_t per_cu = o >= 4 ? 4u : (o >= 3 ? 3u : (o >= 2 ? 2u : 1u));
-        if (per_cu != r->wf_seg_per_cu) { r->wf_seg_per_cu = per_cu; r->wf_pixels = 0; }      /* (the queues are cut anew at the next frame) */
+        r->wf_seg_per_cu = o >= 4 ? 4u : (o >= 3 ? 3u : (o >= 2 ? 2u : 1u));
     } else (void)hipGetLastError();
 }
 
@@ -197,13 +210,21 @@ static void renderer_load_jit(eu_renderer *r, const euclider::JitPlan &plan, con
  * and renderer_poll_jit switches over when it is done. */
 static void renderer_attach_jit(eu_renderer *r, bool async) {
     r->jit.requested = 1;
-    const euclider::JitPlan plan = euclider::jit_generate(*r->flat, r->jit_flags);
+    const euclider::JitPlan plan = euclider::jit_generate(*r->flat, r->jit_flags, r->fuse);
     euclider::JitBuild b;
     const int rc = euclider::jit_build(plan, r->cache_dir, b, async);
     r->jit_log = b.log;
     fill_jit_info(plan, b, false, r->jit);
-    if (rc == EU_OK) { renderer_load_jit(r, plan, b); return; }
-    if (async && rc == EU_ERR_BUSY) r->jit_job = euclider::jit_submit(r->flat, r->cache_dir, r->jit_flags);
+    if (rc == EU_OK) {
+        renderer_load_jit(r, plan, b);
+        if (!r->jit_module && b.from_cache && !async) {      /* a cached code object the runtime refused (truncated, foreign): forget it and compile once */
+            euclider::jit_forget(plan, r->cache_dir);
+            euclider::JitBuild b2;
+            if (euclider::jit_build(plan, r->cache_dir, b2, false) == EU_OK) { r->jit_log = b2.log; renderer_load_jit(r, plan, b2); }
+        }
+        return;
+    }
+    if (async && rc == EU_ERR_BUSY) r->jit_job = euclider::jit_submit(r->flat, r->cache_dir, r->jit_flags, plan.key, r->fuse);
 }
 
 static void renderer_poll_jit(eu_renderer *r) {
@@ -212,8 +233,38 @@ static void renderer_poll_jit(eu_renderer *r) {
     r->jit_job.reset();
     r->jit_log = job->build.log;
     if (job->rc != EU_OK) { fill_jit_info(job->plan, job->build, false, r->jit); return; }
-    (void)hipDeviceSynchronize();      /* frames in flight still run the interpreter kernels on these buffers */
-    renderer_load_jit(r, job->plan, job->build);
+    renderer_load_jit(r, job->plan, job->build);      /* (frames in flight keep running the kernels they were launched with; the buffers stay) */
+}
+
+/* interpreter kernels: producer workgroups per CU from the occupancy of the shade kernel that will be launched (fused or not) */
+template <int D> static void interp_seg_per_cu(eu_renderer *r) {
+    const uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
+    const bool hs_lds = hs_cap <= 24;
+    const size_t isect_lds = hs_lds ? (size_t)(EU_WF_BLOCK / 64) * hs_cap * 64 * (sizeof(real) + 4) : 0;
+    const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(real) * EU_WF_BLOCK;
+    const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !(r->opts.flags & EU_RENDERER_SHADE_SCENE_GLOBAL);
+    const size_t shade_dyn = shade_lds ? (size_t)r->scene_words * 8 + color_lds : color_lds;
+    const bool fuse = r->fuse && hs_lds && shade_lds;
+    const size_t dyn = fuse ? (shade_dyn > isect_lds ? shade_dyn : isect_lds) : shade_dyn;
+    int occ = 0, occ0 = 0;
+    hipError_t e;
+    if (fuse) {
+        if (dyn > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void *)eu_wf_fshade_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            (void)hipFuncSetAttribute((const void *)eu_wf_fshade0_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        }
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, eu_wf_fshade_kernel<D, true>, EU_WF_BLOCK, dyn);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, eu_wf_fshade0_kernel<D, true>, EU_WF_BLOCK, dyn);
+    } else if (shade_lds) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, eu_wf_shade_kernel<D, true>, EU_WF_BLOCK, dyn);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, eu_wf_shade0_kernel<D, true>, EU_WF_BLOCK, dyn);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, eu_wf_shade_kernel<D, false>, EU_WF_BLOCK, dyn);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, eu_wf_shade0_kernel<D, false>, EU_WF_BLOCK, dyn);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return; }
+    const int o = occ < occ0 ? occ : occ0;
+    r->wf_seg_per_cu = o >= 3 ? 3u : (o >= 2 ? 2u : 1u);
 }
 
 static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_scene, int device, const eu_renderer_opts *opts_in, eu_renderer **out, char *err, size_t errlen) {
@@ -263,7 +314,12 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         r->scene_words = (uint32_t)blob.size();
         r->scene_in_lds = blob.size() * 8 <= 60 * 1024;
         r->use_wavefront = r->opts.kernel != EU_KERNEL_STACK;
-        r->wf_n_streams = r->opts.streams ? (int)r->opts.streams : ((h.flags & 1u) ? 2 : 1);      /* branching scenes: two band pipelines fill each other's kernel tails (measured: +8 %); others: -5 % */
+        r->fuse = !(r->opts.flags & EU_RENDERER_NO_FUSE);
+        /* band pipelines per frame: three for a scene whose recursion branches -- with the caller's stream they occupy the runtime's four
+         * hardware queues, and their kernels cover each other's tails (round 4, fused kernels, 3d_room 1080p: 1 / 2 / 3 / 4 bands = 1.86 /
+         * 1.36 / 1.28 / 1.87 ms; 8K: 2 / 3 = 16.4 / 15.1 ms); one for the others, whose frames are chains of small launches (3d_hallways
+         * 0.56 / 0.54 / 0.54 ms, 4d_cylinders 0.45 / 0.46 / 0.51) */
+        r->wf_n_streams = r->opts.streams ? (int)r->opts.streams : ((h.flags & 1u) ? 3 : 1);
         if (r->opts.ray_factor > 0.0) r->wf_ray_factor = (real)r->opts.ray_factor;
         if (r->opts.band_pixels) r->wf_band_pixels = r->opts.band_pixels;
         if (r->opts.split_pixels) r->wf_split_pixels = r->opts.split_pixels;
@@ -284,6 +340,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
         if ((specialize == EU_SPECIALIZE_SYNC || specialize == EU_SPECIALIZE_ASYNC) && r->use_wavefront) renderer_attach_jit(r, specialize == EU_SPECIALIZE_ASYNC);
+        if (r->use_wavefront && !r->jit_intersect0) { if (r->dim == 3) interp_seg_per_cu<3>(r); else interp_seg_per_cu<4>(r); }
         return EU_OK;
     };
     int rc = body();
@@ -313,7 +370,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
-    if (r->jit_job) r->jit_job->cancelled.store(true);      /* (dropped if its turn has not come; the worker keeps its own reference to the scene) */
+    if (r->jit_job) r->jit_job->waiters.fetch_sub(1);      /* (a job nobody waits for any more is dropped if its turn has not come; the worker keeps its own reference to the scene) */
     if (r->jit_module) (void)hipModuleUnload(r->jit_module);
     for (void *p : r->d_textures) (void)hipFree(p);
     for (void *p : r->wf_allocs) (void)hipFree(p);
@@ -413,7 +470,7 @@ static int wf_ensure(eu_renderer *r, size_t pixels, size_t items, uint32_t max_d
         if ((rc = alloc((void **)&B.ray[k], ray_cap * 2 * D * sizeof(real)))) return rc;
         if ((rc = alloc((void **)&B.ray_pa[k], ray_cap * sizeof(uint2)))) return rc;
     }
-    if ((rc = alloc((void **)&B.hit, ray_cap * sizeof(EuWfHit)))) return rc;
+    for (int k = 0; k < 2; k++) if ((rc = alloc((void **)&B.hit[k], ray_cap * sizeof(EuWfHit)))) return rc;
     /* node ids are static: generation g's queue slot q at g*ray_cap + q (only the slots that hold rays are ever touched) */
     if ((rc = alloc((void **)&B.nodes, node_cap * sizeof(EuTsNode)))) return rc;
     if ((rc = alloc((void **)&B.node_kind, node_cap))) return rc;
@@ -494,7 +551,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, band_items, dc.max_depth, n_par, df_in.single_pixel ? 0u : permille);
     if (rc != EU_OK) return rc;
     if (r->prepare_only) return EU_OK;      /* buffers, streams and events exist now: nothing is allocated while the frame is in flight */
-    const bool jit = r->jit_intersect != nullptr;
+    const bool jit = r->jit_intersect0 != nullptr;
     uint32_t hs_cap = r->hit_cap < 8 ? 8u : ((r->hit_cap + 3u) & ~3u);
     if (jit && r->jit_hs_cap) hs_cap = r->jit_hs_cap;      /* (the same unless the plan was tuned: jit.cpp) */
     const bool hs_lds = jit ? r->jit_hs_lds : hs_cap <= 24;      /* two workgroups per CU at least; else: private (scratch) hit stack */
@@ -505,8 +562,12 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(real) * EU_WF_BLOCK;
     const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !(r->opts.flags & EU_RENDERER_SHADE_SCENE_GLOBAL);
     const size_t shade_dyn = jit ? 0 : (shade_lds ? (size_t)r->scene_words * 8 + color_lds : color_lds);
+    /* one launch per generation where a fused kernel exists: the specialised module's, or -- interpreter -- the ones with the hit stack
+     * and the scene copy in LDS (deeper stacks and larger scenes keep the two-kernel pipeline) */
+    const bool fuse = jit ? r->jit_fshade != nullptr : (r->fuse && hs_lds && shade_lds);
+    const size_t fshade_dyn = fuse ? (shade_dyn > isect_lds ? shade_dyn : isect_lds) : shade_dyn;      /* (the hit stack lies over what the shading part no longer needs) */
     unsigned g_isect, g_isect0, g_res;      /* (the generation-0 kernels need more registers; their grids are sized on their own) */
-    if (jit) { if ((rc = wf_grid_module(r, r->jit_intersect, isect_lds, g_isect)) || (rc = wf_grid_module(r, r->jit_intersect0, isect_lds, g_isect0))) return rc; }
+    if (jit) { if ((rc = wf_grid_module(r, r->jit_intersect0, isect_lds, g_isect0)) || (rc = r->jit_intersect ? wf_grid_module(r, r->jit_intersect, isect_lds, g_isect) : ((g_isect = g_isect0), EU_OK))) return rc; }
     else if (hs_small) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 16>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 16>, 0, g_isect0))) return rc; }
     else if (!hs_lds) { if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 96>, 0, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 96>, 0, g_isect0))) return rc; }
     else if ((rc = wf_grid(r, eu_wf_intersect_kernel<D, 0>, isect_lds, g_isect)) || (rc = wf_grid(r, eu_wf_intersect0_kernel<D, 0>, isect_lds, g_isect0))) return rc;
@@ -537,6 +598,10 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
             sts[k] = side_streams ? r->wf_stream[k] : caller_stream;
             Bs[k] = r->wf[side_streams ? k : 0];
             Bs[k].pad = band0 + k;
+            {   /* producers: at most what the producer kernel's occupancy gives (the buffers may have been cut for more) */
+                const unsigned want = share((unsigned)(r->num_cus * r->wf_seg_per_cu));
+                if (want < Bs[k].n_seg) Bs[k].n_seg = want;
+            }
             if (df.single_pixel) { df.band_row0 = 0; df.band_rows = 1; df.root_base = 0; Bs[k].npix = 1u; }
             else if (interleaved) {
                 const uint32_t groups = (n_groups - k + (uint32_t)n_par - 1) / (uint32_t)n_par;      /* groups k, k + n, ... < n_groups */
@@ -565,28 +630,48 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
                 hipStream_t stream = sts[k];
                 const unsigned g_prod = B.n_seg;      /* producers: one output segment per workgroup */
                 real time_s = df.time_s;
-                if (jit && g == 0) {
-                    void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&hit_t};
-                    HIP_TRY(hipModuleLaunchKernel(r->jit_intersect0, g_isect0, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
-                    void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
-                    HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
-                } else if (jit) {
-                    void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&gen, (void *)&B, (void *)&counters};
-                    HIP_TRY(hipModuleLaunchKernel(r->jit_intersect, g_isect, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
-                    void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
-                    HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
-                } else if (g == 0) {
-                    if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 0>), dim3(g_isect0), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, cam, df, B, counters, hit_t);
-                    else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 16>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, cam, df, B, counters, hit_t);
-                    else hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 96>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, cam, df, B, counters, hit_t);
-                    if (shade_lds) hipLaunchKernelGGL((eu_wf_shade0_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
-                    else hipLaunchKernelGGL((eu_wf_shade0_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
+                const bool tail = fuse;                        /* this launch also intersects the rays it queues (the last generation queues none) */
+                const bool isect_now = !fuse || g == 0;        /* ... so only generation 0 has an intersect launch of its own */
+                if (jit) {
+                    if (isect_now && g == 0) {
+                        void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&hit_t};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_intersect0, g_isect0, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
+                    } else if (isect_now) {
+                        void *ia[] = {(void *)&scene, (void *)&hs_cap, (void *)&gen, (void *)&B, (void *)&counters};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_intersect, g_isect, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)isect_lds, stream, ia, nullptr));
+                    }
+                    if (g == 0 && tail) {
+                        void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&hs_cap, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_fshade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)fshade_dyn, stream, sa, nullptr));
+                    } else if (g == 0) {
+                        void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                    } else if (tail) {
+                        void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&hs_cap, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_fshade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)fshade_dyn, stream, sa, nullptr));
+                    } else {
+                        void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                    }
                 } else {
-                    if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, gen, B, counters);
-                    else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, gen, B, counters);
-                    else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, gen, B, counters);
-                    if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
-                    else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+                    if (isect_now && g == 0) {
+                        if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 0>), dim3(g_isect0), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, cam, df, B, counters, hit_t);
+                        else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 16>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, cam, df, B, counters, hit_t);
+                        else hipLaunchKernelGGL((eu_wf_intersect0_kernel<D, 96>), dim3(g_isect0), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, cam, df, B, counters, hit_t);
+                    } else if (isect_now) {
+                        if (hs_lds) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 0>), dim3(g_isect), dim3(EU_WF_BLOCK), isect_lds, stream, scene, hs_cap, gen, B, counters);
+                        else if (hs_small) hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 16>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 16u, gen, B, counters);
+                        else hipLaunchKernelGGL((eu_wf_intersect_kernel<D, 96>), dim3(g_isect), dim3(EU_WF_BLOCK), 0, stream, scene, 96u, gen, B, counters);
+                    }
+                    if (g == 0 && tail) hipLaunchKernelGGL((eu_wf_fshade0_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), fshade_dyn, stream, scene, r->scene_words, hs_cap, cam, df, B, counters, rgba, hit_t, point);
+                    else if (g == 0) {
+                        if (shade_lds) hipLaunchKernelGGL((eu_wf_shade0_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
+                        else hipLaunchKernelGGL((eu_wf_shade0_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, cam, df, B, counters, rgba, hit_t, point);
+                    } else if (tail) hipLaunchKernelGGL((eu_wf_fshade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), fshade_dyn, stream, scene, r->scene_words, hs_cap, gen, max_depth, time_s, B, counters, rgba, point);
+                    else {
+                        if (shade_lds) hipLaunchKernelGGL((eu_wf_shade_kernel<D, true>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+                        else hipLaunchKernelGGL((eu_wf_shade_kernel<D, false>), dim3(g_prod), dim3(EU_WF_BLOCK), shade_dyn, stream, scene, r->scene_words, gen, max_depth, time_s, B, counters, rgba, point);
+                    }
                 }
             }
         }

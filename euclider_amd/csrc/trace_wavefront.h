@@ -74,7 +74,7 @@
 #define EU_SHADE_TAKE_CHUNKS 1
 #endif
 #ifndef EU_WF_SPREAD
-#define EU_WF_SPREAD 1u       /* a shade window is made of this many pieces from equally spaced places of the generation's queue */
+#define EU_WF_SPREAD 0        /* 1: a shade window is made of 256-ray pieces from equally spaced places of the generation's queue (each workgroup a sample of the whole) */
 #endif
 #ifndef EU_WF_DEAL_FACTOR
 #define EU_WF_DEAL_FACTOR 4u
@@ -85,7 +85,10 @@
                                                   * counter, a claim per ~6 us batch each, is the ~88 claims per microsecond at which one word saturates: with 8 classes the
                                                   * claims' latency grew beyond the batch that was to hide it */
 #endif
-#define EU_WORK_PER_GEN ((EU_WORK_SHARDS + 1u) * EU_WORK_STRIDE)   /* + the shade kernel's window counter */
+#define EU_WORK_WINDOWS (EU_WORK_SHARDS * EU_WORK_STRIDE)             /* the shade kernel's window counter */
+#define EU_WORK_TOTAL ((EU_WORK_SHARDS + 1u) * EU_WORK_STRIDE)      /* rays queued for this generation (summed by the producers: one atomic per workgroup that queued any) */
+#define EU_WORK_SLOTS (EU_WORK_SHARDS + 2u)
+#define EU_WORK_PER_GEN (EU_WORK_SLOTS * EU_WORK_STRIDE)
 
 #if defined(EU_PROFILE_SHADE_WAVE)      /* diagnostic build: wave-level shares of the shade kernel (LDS rows, first active lane: trace_device.h SHP): STAMP(k) closes
                                          * section k-1 (STAMP(0): what lies between two batches -> 15), SUB(k) closes sub-section k; sections do not overlap */
@@ -112,7 +115,8 @@ static_assert(sizeof(EuWfHit) == 16, "one 16-byte store per ray");
 struct EuWfBuffers {
     real *ray[2];             /* [ray_cap] EuWfRay<D>: origin then direction; ping-pong by generation */
     uint2 *ray_pa[2];           /* x: node id that receives this ray's colour; y: entity the ray travels in (bits 0..15) | delivery slot / mode (bits 16..18) */
-    EuWfHit *hit;               /* per ray of the current generation */
+    EuWfHit *hit[2];            /* per ray of a generation, ping-pong by generation like the rays (the fused kernel writes generation g + 1's while other
+                                 * workgroups still read generation g's) */
     /* tree nodes (trace_nodes.h): one id per traced ray in queue order, only the slots of rays that need one are touched */
     EuTsNode *nodes;            /* [node_cap] */
     uint8_t *node_kind;         /* [node_cap] TS_NONE / TS_OVER / ...: what resolve has to do for the ray in this slot */
@@ -355,6 +359,8 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
                               const EuWfBuffers &B, EuDevCounters *counters, eu_f64 *__restrict__ hit_t_aov, uint64_t *lds_dyn) {
     constexpr bool g0 = G0;
     WF_PROF_BEGIN();
+    /* an empty generation (3d_hallways at depth 12: the last five) costs a launch, not a prologue: one scalar load says so */
+    if (!g0 && B.work[gen * EU_WORK_PER_GEN + EU_WORK_TOTAL] == 0u) { WF_PROF_END(B, 0, gen); return; }
     EuScene S;
     S.init(scene_g);      /* wave-uniform addresses: the scene arrives through scalar loads */
     typename eu_conditional<HSCAP == 0, HitStackLds, HitStackPriv<(HSCAP ? HSCAP : 1)>>::type HS;
@@ -420,7 +426,7 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
 #if EU_REAL_BITS == 32
                     h.pad = 0;
 #endif
-                    B.hit[i] = h;
+                    B.hit[in][i] = h;
                     live = false;
                 }
                 }
@@ -467,7 +473,7 @@ EU_DEV void wf_intersect_body(const uint64_t *__restrict__ scene_g, uint32_t hs_
 #if EU_REAL_BITS == 32
                 h.pad = 0;
 #endif
-                B.hit[i] = h;
+                B.hit[in][i] = h;
             }
             if (g0 && hit_t_aov) hit_t_aov[out_idx] = have ? best_t : -R(1.0);
             }
@@ -501,12 +507,22 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_wf_intersect0_
 }
 
 /* ------------------------------------------------------------------ ComposableSurface::get_color up to the recursive calls */
-template <int D, bool SCENE_LDS, class P, bool G0>
+/* FUSE: the kernel goes on to INTERSECT the rays it has just queued (generation g + 1: they sit in this workgroup's own segment), so
+ * that a generation costs one launch instead of two -- one prologue, one kernel tail -- and the chain of dependent launches of a
+ * frame is a third shorter (a 64x64 frame, or 3d_hallways' thin late generations, are nothing but that chain).  FUSE = -1: no; else
+ * the hit stack of the intersect part (0: in LDS with capacity hs_cap, over the dynamic LDS the shading part no longer needs; > 0: a
+ * private array of that many entries). */
+template <int D, bool SCENE_LDS, class P, bool G0, int FUSE = -1>
 EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t gen, uint32_t max_depth, real time_s, const EuDevCamera &cam, const EuDevFrame &fr,
                           const EuWfBuffers &B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb,
-                          uint64_t *lds_dyn) {
+                          uint64_t *lds_dyn, uint32_t hs_cap = 0) {
     constexpr bool g0 = G0;
     WF_PROF_BEGIN();
+    if (!g0 && B.work[gen * EU_WORK_PER_GEN + EU_WORK_TOTAL] == 0u) {      /* an empty generation: this workgroup's output segment is empty too */
+        if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = 0u;
+        WF_PROF_END(B, 1, gen);
+        return;
+    }
     __shared__ uint32_t seg_fill;
     if (threadIdx.x == 0) seg_fill = 0;
     __syncthreads();
@@ -571,14 +587,9 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
 #endif
         }
         const uint32_t n_win = (total + win - 1) / win;
-#if EU_WF_SPREAD > 1
-        uint32_t piece = win;      /* (pieces are powers of two; a window that is none stays in one piece) */
-        if ((win & (win - 1u)) == 0u) piece = win / EU_WF_SPREAD >= EU_WF_BLOCK ? win / EU_WF_SPREAD : EU_WF_BLOCK;
-        const uint32_t pshift = (piece & (piece - 1u)) == 0u ? (uint32_t)__builtin_ctz(piece) : 0u;
-#endif
 #if EU_WF_DEAL_SHADE
         const bool dealt = n_win > gridDim.x;
-        uint32_t *win_ctr = B.work + gen * EU_WORK_PER_GEN + EU_WORK_SHARDS * EU_WORK_STRIDE;
+        uint32_t *win_ctr = B.work + gen * EU_WORK_PER_GEN + EU_WORK_WINDOWS;
 #endif
         for (uint32_t w = blockIdx.x; w < n_win;) {
 #if EU_WF_DEAL_SHADE
@@ -590,18 +601,16 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
             uint32_t myq[EU_WF_WIN / EU_WF_BLOCK], mykey[EU_WF_WIN / EU_WF_BLOCK], myrank[EU_WF_WIN / EU_WF_BLOCK];
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
-                /* window w = the w-th piece of each of `spread` equal parts of the generation: a workgroup's rays come from several places
-                 * (a producer's output is sorted by what its rays hit, so neighbouring rays cost alike), each piece still contiguous */
                 const uint32_t kb = k * EU_WF_BLOCK;
-#if EU_WF_SPREAD > 1      /* (a piece is a multiple of the block: every thread of slot k is in the same piece, and the address arithmetic is scalar) */
-                const uint32_t v = (piece == win ? w * win + kb : (((kb >> pshift) * n_win + w) << pshift) + (kb & (piece - 1u))) + threadIdx.x;
+#if EU_WF_SPREAD      /* window w = every n_win-th 256-ray piece of the generation's queue, starting with piece w (the arithmetic is scalar) */
+                const uint32_t v = (w + k * n_win) * EU_WF_BLOCK + threadIdx.x;
 #else
                 const uint32_t v = w * win + kb + threadIdx.x;
 #endif
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
                 if (kb < win && v < total) {
                     myq[k] = g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v);
-                    const uint32_t he = B.hit[myq[k]].ent;
+                    const uint32_t he = B.hit[in][myq[k]].ent;
                     if (he == EU_WF_ENT_DEAD) B.node_kind[node_base + myq[k]] = (uint8_t)TS_NONE;      /* (generation 0 only) nothing to shade, nothing to resolve */
                     else {
                         mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
@@ -649,7 +658,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                 WF_STAMP(1);
                 uint32_t parent, ent, sm;
                 real o[D], d[D];
-                const EuWfHit hit = B.hit[i];
+                const EuWfHit hit = B.hit[in][i];
                 uint32_t hit_ent = hit.ent;
                 if (g0) {
                     const EuPrimary pr = wf_primary_ray<D, P>(S, cam, fr, cam_ent, i, o, d);
@@ -787,7 +796,47 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
+    if constexpr (FUSE >= 0) {
+        /* trace_closest of this workgroup's own children (the barrier above made their records visible to all its waves; the same
+         * compute unit wrote them, so its L1 holds nothing stale).  Batches of 64 in queue order; the four waves take them in turn. */
+        const uint32_t n_own = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
+        if (n_own != 0u) {
+            EuScene S2;
+            S2.init(scene_g);      /* (the intersect part reads the scene through scalar loads from device memory, whatever the shading part used) */
+            typename eu_conditional<FUSE == 0, HitStackLds, HitStackPriv<(FUSE > 0 ? FUSE : 1)>>::type HS;
+            if constexpr (FUSE == 0) {
+                const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                real *hs_t = (real *)(lds_dyn);
+                uint32_t *hs_c = (uint32_t *)(hs_t + (EU_WF_BLOCK / 64) * hs_cap * 64);
+                HS.t = hs_t + wave * hs_cap * 64 + lane;
+                HS.c = hs_c + wave * hs_cap * 64 + lane;
+                HS.cap = hs_cap;
+            }
+            for (uint32_t idx = threadIdx.x; idx - (threadIdx.x & 63u) < n_own; idx += EU_WF_BLOCK) {
+                if (idx < n_own) {
+                    const uint32_t q = out_base + idx;
+                    real o[D], d[D];
+                    wf_load_ray<D>(B, outb, q, o, d);
+                    bool have = false, fail = false;
+                    real best_t = R(0.0);
+                    uint32_t best_code = 0, best_ent = EU_WF_ENT_MISS;
+                    cnt.rays++;
+                    P::trace_closest(S2, o, d, HS, cnt, 2, fail, have, best_t, best_code, best_ent);
+                    EuWfHit h;
+                    h.t = best_t; h.code = best_code; h.ent = best_ent;
+#if EU_REAL_BITS == 32
+                    h.pad = 0;
+#endif
+                    B.hit[outb][q] = h;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t queued = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
+        B.seg_count[(gen + 1) * B.n_seg + blockIdx.x] = queued;
+        if (queued) atomicAdd(B.work + (gen + 1) * EU_WORK_PER_GEN + EU_WORK_TOTAL, queued);
+    }
     wf_flush_counters(counters, cnt);
     WF_PROF_END(B, 1, gen);
 }
@@ -807,6 +856,22 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kern
     wf_shade_body<D, SCENE_LDS, EuInterp<D>, true>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn);
 }
 
+/* the fused forms (interpreter: hit stack in LDS only -- scenes whose stack is deeper keep the two-kernel pipeline) */
+template <int D, bool SCENE_LDS>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_fshade_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t max_depth, real time_s,
+                                                                   EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
+    extern __shared__ uint64_t lds_dyn[];
+    const EuDevCamera cam = {};
+    const EuDevFrame fr = {};
+    wf_shade_body<D, SCENE_LDS, EuInterp<D>, false, 0>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn, hs_cap);
+}
+template <int D, bool SCENE_LDS>
+__global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_fshade0_kernel(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,
+                                                                    EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ hit_t_aov, eu_f64 *__restrict__ point_rgb) {
+    extern __shared__ uint64_t lds_dyn[];
+    wf_shade_body<D, SCENE_LDS, EuInterp<D>, true, 0>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn, hs_cap);
+}
+
 /* ------------------------------------------------------------------ bottom-up resolve of one generation's nodes
  * (surface_palette.over(transition_palette), both quantised to u8: surface.rs:104-114; combine: surface.rs:159-161);
  * a node of generation 0 delivers to its pixel (trace_nodes.h): there is no separate final pass.
@@ -816,6 +881,7 @@ __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_wf_shade0_kern
  * of 19; the launch is bound by its node traffic -- 64-byte records, 32-byte deliveries -- and wants the whole chip's worth of waves.) */
 __global__ __launch_bounds__(EU_WF_BLOCK) void eu_wf_resolve_kernel(uint32_t gen, uint32_t total0, EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {
     WF_PROF_BEGIN();
+    if (gen != 0 && B.work[gen * EU_WORK_PER_GEN + EU_WORK_TOTAL] == 0u) { WF_PROF_END(B, 2, gen); return; }
     LaneCounters cnt = {0, 0, 0, 0};
     const uint32_t node_base = gen * B.ray_cap;
     const bool g0 = gen == 0;

@@ -133,6 +133,8 @@ int eu_device_count(void);
                                       object already in a cache is used from the first frame on. */
 #define EU_RENDERER_SHADE_SCENE_GLOBAL 1u   /* flags: the interpreter's shade kernel reads the scene from global memory, not from its LDS copy
                                                (what scenes above ~40 KB get anyway; here so that tests can reach that variant) */
+#define EU_RENDERER_NO_FUSE 2u               /* flags: one intersect and one shade launch per generation (rounds 1-3) instead of the fused kernel that shades a
+                                               generation and intersects the rays it has just queued (A/B checks; the frames are the same) */
 typedef struct {
     uint32_t struct_size;        /* sizeof(eu_renderer_opts) of the caller: the struct may grow */
     uint32_t kernel;             /* EU_KERNEL_* */

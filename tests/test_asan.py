@@ -44,7 +44,7 @@ for path in sorted(glob.glob("scenes/*.json")):
     for low in (False,):
         env = Parser().parse_file(path)
         src, key = env.jit_source()          # the generator walks the whole flat scene
-        assert "eu_jit_shade" in src and len(key) == 32
+        assert "eu_jit_fshade" in src and len(key) == 32
         env.close(); n += 1
 for bad in ("", "{", "[]", '{"Universe3": []}', '{"Nope": {}}', '{"Universe3": {"camera": 1, "entities": [], "background": 2}}'):
     try:

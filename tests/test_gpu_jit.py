@@ -153,3 +153,36 @@ def test_full_hit_stack_retraces_the_frame(scene, depth, tmp_path):
     assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
     both_nan = np.isnan(img.hit_t) & np.isnan(ref.hit_t)
     assert np.array_equal(img.hit_t[~both_nan], ref.hit_t[~both_nan])
+
+
+def test_full_hit_stack_on_the_sequence_and_single_pixel_paths(tmp_path):
+    """Round 4 (ADVICE): a full hit stack has its own counter (EuDevCounters::hs_full) and every entry point that hands out pixels
+    falls back to the stack kernel by itself: eu_sequence_next traces the frame again when it is collected, eu_trace_screen_point
+    traces the pixel again -- neither returns a colour made of a dropped hit -- and the plainly asynchronous eu_render_device reports
+    what happened (EU_ERR_CAPACITY with a text that names the hit stack, not the ray queues)."""
+    import torch
+    from euclider_amd import FrameSequence, Parser, _capi
+    from euclider_amd.environment import EuError
+    path = os.path.join(SCENES, "3d_room.json")
+    good = Parser().parse_file(path).configure(specialize="off")
+    good.camera.max_depth = 5
+    ref = good.render((160, 90))
+    pts = [good.trace_screen_point(0.0, 5, x, y, 160, 90) for (x, y) in ((80, 45), (100, 30), (3, 3))]
+    good.close()
+    env = Parser().parse_file(path).configure(specialize="sync", cache_dir=str(tmp_path), jit_flags="-DEU_TEST_HS_FULL")
+    env.camera.max_depth = 5
+    assert env.jit_info()["active"]
+    with FrameSequence(env, (160, 90), slots=2) as seq:
+        seq.submit((160, 90))
+        seq.submit((160, 90))
+        frames = [seq.next(), seq.next()]
+    assert all(np.array_equal(f.data, ref.data) and f.stats == ref.stats for f in frames)
+    assert env.retraces() == 2
+    assert [env.trace_screen_point(0.0, 5, x, y, 160, 90) for (x, y) in ((80, 45), (100, 30), (3, 3))] == pts
+    assert env.retraces() >= 3          # (a pixel whose ray meets no box needs no second trace)
+    rgba = torch.zeros((90, 160), dtype=torch.int32, device="cuda:0")
+    env.render_device(env.frame(160, 90, time=0.0, rows=(0, 90)), rgba.data_ptr(), None, torch.cuda.current_stream().cuda_stream, device=0)
+    with pytest.raises(EuError) as ei:
+        env.stats(device=0)
+    assert ei.value.code == _capi.EU_ERR_CAPACITY and "hit stack" in str(ei.value)
+    env.close()

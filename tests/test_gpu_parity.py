@@ -5,6 +5,7 @@ Bar: RGB8 bit-exact, ray/background counters identical, primary hit distance ide
 unless noted).  Sizes are chosen so the oracle finishes in seconds.
 """
 import os
+import ctypes as C
 
 import numpy as np
 import pytest
@@ -401,4 +402,47 @@ def test_render_multi_two_frames_in_flight(ray_factor):
         assert g.data.shape == w.data.shape and np.array_equal(g.data, w.data) and g.stats == w.stats
     pose(env, frames[0][3])
     assert np.array_equal(env.render_multi(frames[0][0], devs, time=frames[0][1], rows=frames[0][2]).data, want[0].data)      # the one-call form still works afterwards
+    env.close()
+
+
+@pytest.mark.parametrize("scene,depth,W,H", [("3d_room.json", 8, 1000, 563), ("3d_hallways.json", 12, 960, 540), ("4d_frame.json", 6, 640, 360),
+                                             ("4d_cylinders.json", 5, 320, 180), ("3d_photo.json", 6, 333, 187)])
+def test_pipeline_forms_agree(scene, depth, W, H):
+    """Round 4: how a frame is cut and launched does not show in it.  One to four concurrent band pipelines (interleaved 8-row groups,
+    frames large enough to be split), the fused kernel (shade a generation, intersect the rays just queued) against the two-kernel
+    pipeline, shade windows spread over the queue, batches and windows dealt through counters: every form gives the oracle's frame,
+    counters included."""
+    from euclider_amd import Parser, _capi
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, scene)
+    orgb, _, ost = load_scene_file(path).render(W, H, max_depth=depth)
+    forms = [dict(streams=1), dict(streams=2, split_pixels=4096), dict(streams=3, split_pixels=4096), dict(streams=4, split_pixels=4096),
+             dict(streams=1, flags=_capi.EU_RENDERER_NO_FUSE), dict(streams=3, split_pixels=4096, flags=_capi.EU_RENDERER_NO_FUSE),
+             dict(streams=2, split_pixels=4096, band_grid_permille=400)]
+    from euclider_amd import environment
+    if environment.DEFAULT_RENDERER_OPTS.get("specialize") == "sync":      # the tuning flags reach the specialised kernels only
+        forms += [dict(streams=2, split_pixels=4096, jit_flags="-DEU_WF_SPREAD=1"), dict(streams=1, jit_flags="-DEU_WF_DEAL_ISECT=1 -DEU_WF_DEAL_SHADE=1 -DEU_WF_WIN_MIN=256"),
+                  dict(streams=2, split_pixels=4096, flags=_capi.EU_RENDERER_NO_FUSE, jit_flags="-DEU_WF_DEAL_ISECT=1 -DEU_WF_DEAL_SHADE=1 -DEU_WF_WIN=512"),
+                  dict(streams=1, jit_flags="-DEU_WF_EQUAL_WIN=0 -DEU_SHADE_TAKE_CHUNKS=0")]
+    for form in forms:
+        env = Parser().parse_file(path).configure(**form)
+        env.camera.max_depth = depth
+        img = env.render((W, H))
+        env.close()
+        assert np.array_equal(img.data, orgb), form
+        assert img.stats["rays"] == ost["rays"] and img.stats["bg_samples"] == ost["bg_samples"], form
+
+
+def test_renderer_error_text():
+    """eu_renderer_error: what the most recent failing call on a renderer had to say."""
+    from euclider_amd import Parser, _capi
+    env = Parser().parse_file(os.path.join(SCENES, "3d_fresnel.json"))
+    L, r = env._L, env.renderer()
+    assert (L.eu_renderer_error(r) or b"") == b""
+    cam = _capi.Camera.from_buffer_copy(env.camera)
+    cam.dim = 4
+    fr = env.frame(8, 8, time=0.0, rows=(0, 8))
+    out = np.zeros((8, 8, 3), dtype=np.uint8)
+    assert L.eu_render(r, C.byref(cam), C.byref(fr), out.ctypes.data, None, None) == _capi.EU_ERR_INVALID_ARGUMENT
+    assert b"dimension" in L.eu_renderer_error(r)
     env.close()

@@ -21,7 +21,7 @@ def test_generator_on_every_shipped_scene(low_precision):
         again, key2 = env.jit_source()
         assert src == again and key == key2 and len(key) == 32          # deterministic: the cache is keyed by content
         keys.add(key)
-        for name in ("eu_jit_intersect0", "eu_jit_intersect", "eu_jit_shade0", "eu_jit_shade", "struct EuJit", "trace_closest", "material_at"):
+        for name in ("eu_jit_intersect0", "eu_jit_fshade0", "eu_jit_fshade", "struct EuJit", "trace_closest", "material_at"):      # (the default module: the fused pipeline)
             assert name in src, (path, name)
         # one inside-test function per entity root, one trace_closest block per surfaced entity
         assert src.count("/* entity ") >= 1
