@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps between two synchronisations) is run this many times; value and ms_per_step are the MEDIAN region, "
                          "config.timed_regions carries min / median / max")
+    ap.add_argument("--no-alone", action="store_true", help="skip the one-frame-at-a-time measurement (profiling passes: only the timed region's launches)")
     ap.add_argument("--abi-child", type=int, default=0,
                     help="internal: ONE process drives this many GPUs through the C ABI (eu_render_multi) on the 8K frame and prints a JSON object")
     return ap.parse_args()
@@ -322,6 +323,26 @@ def other_configs(torch, dev, Parser, args, in_flight):
                                           ("4d_cylinders.json", 1920, 1080, 8, 32, False), ("3d_room.json", 7680, 4320, 8, 6, False),
                                           ("3d_room.json", 1920, 1080, 10, 40, False), ("3d_room.json", 1920, 1080, 8, 40, True)):
         R = min(in_flight, 2) if W * H > (4 << 20) else in_flight
+        # one frame at a time on a renderer with the library's defaults (the reference's call shape), before the slots' renderers exist
+        ea = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
+        ea.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
+        ea.camera.max_depth = depth
+        frame0 = ea.frame(W, H, time=0.0, rows=(0, H))
+        rgba0 = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        rgb0 = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
+        raw = torch.cuda.current_stream(dev).cuda_stream
+        ts = []
+        for k in range(2 + (4 if W * H > (4 << 20) else 9)):
+            t1 = time.perf_counter()
+            ea.render_device(frame0, rgba0.data_ptr(), None, raw, device=dev.index)
+            ea.pack_rgb_device(rgba0.data_ptr(), rgb0.data_ptr(), H * W, raw, device=dev.index)
+            torch.cuda.synchronize(dev)
+            if k >= 2:
+                ts.append((time.perf_counter() - t1) * 1e3)
+        ts.sort()
+        alone_kms = ea.kernel_ms_history(4, device=dev.index)
+        ea.close()
+        del rgba0, rgb0
         envs = []
         while len(envs) < R:
             e = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
@@ -357,28 +378,13 @@ def other_configs(torch, dev, Parser, args, in_flight):
         gold = golden_frames().get(key)
         sha = hashlib.sha256(rgb[0][:H * W * 3].cpu().numpy().tobytes()).hexdigest()
         vs_oracle = None if gold is None else {"frame_equal": sha == gold["sha256"], "rays_equal": int(st["rays"]) == gold["rays"], "bytes_compared": gold["bytes"]}
-        # one frame at a time on a renderer with the library's defaults (the reference's call shape)
-        ea = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
-        ea.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
-        ea.camera.max_depth = depth
-        raw = torch.cuda.current_stream(dev).cuda_stream
-        ts = []
-        for k in range(2 + (4 if W * H > (4 << 20) else 9)):
-            t1 = time.perf_counter()
-            ea.render_device(frame, rgba[0].data_ptr(), None, raw, device=dev.index)
-            ea.pack_rgb_device(rgba[0].data_ptr(), rgb[0].data_ptr(), H * W, raw, device=dev.index)
-            torch.cuda.synchronize(dev)
-            if k >= 2:
-                ts.append((time.perf_counter() - t1) * 1e3)
-        ts.sort()
-        ea.close()
         kernel_ms = dt * 1e3      # a frame's share of the device (frames overlap; see the headline's roofline)
         alg = 4.0 * W * H + 16.0 * st["bg_samples"] + env.info.flat_bytes
         ach = alg / (kernel_ms * 1e-3) / 1e9
         out.append({"workload": "%s %dx%d depth %d%s" % (scene, W, H, depth, ", low_precision (F = f32, its own rays and pixels)" if lp else ""),
                     "dtype": "f32" if lp else "f64", "value": st["rays"] / dt / 1e6, "unit": "Mray/s",
                     "ms_per_step": dt * 1e3, "steps": steps, "frames_in_flight": R, "slots_agree": agree, "vs_oracle": vs_oracle, "rays_per_frame": int(st["rays"]),
-                    "one_frame_alone": {"ms": ts[len(ts) // 2], "Mray/s": st["rays"] / ts[len(ts) // 2] / 1e3, "frames": len(ts)},
+                    "one_frame_alone": {"ms": ts[len(ts) // 2], "Mray/s": st["rays"] / ts[len(ts) // 2] / 1e3, "frames": len(ts), "kernel_ms": sum(alone_kms) / max(1, len(alone_kms))},
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": None if lp else load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
@@ -507,7 +513,33 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
-        for k in range(max(warmup, n_slots)):      # (every slot's renderer sizes its buffers on its first frame)
+        # every slot's renderer sizes its work buffers on its first frame; should the device run out of memory (eight slots of a large
+        # weak-scaled frame), the run goes on with fewer frames in flight -- all ranks agree on the number -- instead of dying
+        from euclider_amd.environment import EuError
+        while True:
+            ok = 1
+            try:
+                for k in range(n_slots):
+                    step(k)
+                torch.cuda.synchronize(dev)
+            except (EuError, RuntimeError) as e:
+                if n_slots == 1:
+                    raise
+                ok = 0
+                print("bench.py: rank %d: %d frames in flight do not fit (%s); trying %d" % (rank, n_slots, str(e)[:120], max(1, n_slots // 2)), file=sys.stderr, flush=True)
+            if world > 1:
+                t_ok = torch.tensor([ok], device=torch.device("cpu") if smoke_gloo else dev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = int(t_ok.item())
+            if ok:
+                break
+            n_slots = max(1, n_slots // 2)
+            for sl in slots[n_slots:]:
+                sl["env"].close()
+            del slots[n_slots:]
+            del envs[n_slots:]
+            torch.cuda.empty_cache()
+        for k in range(warmup):
             step(k)
         regions = []
         rdev = torch.device("cpu") if smoke_gloo else dev
@@ -531,19 +563,17 @@ def main():
         if world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         return {"W": W, "H": H, "elapsed": elapsed, "regions": regions, "rays": tot[0].item(), "panic": tot[2].item(), "st": st, "kms": kms,
-                "local_rows": local_rows, "rgb_out": slots[0]["rgb_out"], "steps": steps, "slots_agree": same, "step": step, "sync": sync, "slots": slots}
+                "local_rows": local_rows, "rgb_out": slots[0]["rgb_out"], "steps": steps, "slots_agree": same, "step": step, "sync": sync, "slots": slots, "n_slots": n_slots}
 
     parity_failed = False
     W, H = (args.width, args.height) if args.fixed_frame else frame_dims(args.width, args.height, world)
-    run = timed_run(W, H, args.steps, args.warmup, in_flight, args.repeats)
-    elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
-    tot = [run["rays"], 0.0, run["panic"]]
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
+    alone_rgb = None
+    # (measured FIRST, before the renderers of the pipelined run exist: the HIP runtime deals streams to its hardware queues as they come, and with the
+    # eight slots' streams alive a renderer's three band streams shared queues -- 1.60 instead of 1.28 ms in the same process)
     # ONE frame at a time -- the reference's call shape (Environment::render is synchronous: simulation.rs:86, universe/mod.rs:300-357): a
     # renderer with the library's own defaults (its band pipelines on its own streams), launch + pack + wait, frame after frame
     alone = None
-    if world == 1:
+    if world == 1 and not args.no_alone:
         ea = make_env(streams=args.streams)
         frame1 = ea.frame(W, H, time=0.0, rows=(0, H))
         rgba1 = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -559,13 +589,22 @@ def main():
                 ts.append((time.perf_counter() - t1) * 1e3)
         ts.sort()
         akms = ea.kernel_ms_history(8, device=local_rank)
-        alone = {"ms": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "frames": len(ts), "Mray/s": rays_per_step / ts[len(ts) // 2] / 1e3,
-                 "kernel_ms": sum(akms) / max(1, len(akms)), "same_frame": bool(torch.equal(rgb1[:H * W * 3], rgb_out[:H * W * 3])),
+        alone = {"ms": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "frames": len(ts), "Mray/s": ea.stats(device=local_rank)["rays"] / ts[len(ts) // 2] / 1e3,
+                 "kernel_ms": sum(akms) / max(1, len(akms)),
                  "band_streams": args.streams or "library default",
                  "note": "launch, pack, wait -- repeat: one renderer with the library's defaults, nothing else in flight (host launch time and the final wait included; kernel_ms = HIP events around the frame's pipeline)"}
+        alone_rgb = rgb1[:H * W * 3].clone()
         ea.close()
         del rgba1, rgb1
 
+    run = timed_run(W, H, args.steps, args.warmup, in_flight, args.repeats)
+    elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
+    tot = [run["rays"], 0.0, run["panic"]]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    if alone is not None and alone_rgb is not None and rank == 0:
+        alone["same_frame"] = bool(torch.equal(alone_rgb, run["rgb_out"][:H * W * 3]))
+    del alone_rgb
     cfg5 = cfg5_abi = None
     if world > 1 and not args.fixed_frame:      # BASELINE config 5 next to the weak-scaling value: the 8K frame over the same ranks (strong scaling)
         r5 = timed_run(7680, 4320, 4, 1, min(in_flight, 2))
@@ -605,7 +644,7 @@ def main():
             "config": {"workload": workload + (" low_precision (F = f32: a separate mode, not the headline)" if args.low_precision else ""), "scene": args.scene, "width": W, "height": H, "max_depth": args.max_depth,
                        "rays_per_frame": int(rays_per_step), "mpixel_per_s": W * H * args.steps / elapsed / 1e6,
                        "would_panic_events": int(tot[2]),
-                       "frames_in_flight": in_flight, "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "band_streams_per_frame": band_streams or "library default (2 for this scene)",
+                       "frames_in_flight": run["n_slots"], "gpu_max_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "band_streams_per_frame": band_streams or "library default",
                        "one_frame_alone": alone,
                        "timed_regions": {"repeats": len(run["regions"]), "ms_per_step_min": min(run["regions"]) / args.steps * 1e3,
                                          "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": max(run["regions"]) / args.steps * 1e3},
@@ -636,9 +675,13 @@ def main():
                              "checked_against": "oracle/ (CPU restatement), same scene, camera, frame"}
         if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json" and not args.low_precision:
             del rgb_out
+            run = None
+            for e in envs:      # (their streams would share hardware queues with the next renderers' band streams)
+                e.close()
+            del envs[:]
             out["other_configs"] = other_configs(torch, dev, Parser, args, in_flight)
         print(json.dumps(out), flush=True)
-        if out.get("parity", {}).get("mismatch") or not run["slots_agree"]:
+        if out.get("parity", {}).get("mismatch") or not out["config"]["slots_agree"]:
             parity_failed = True
     for e in envs:
         e.close()

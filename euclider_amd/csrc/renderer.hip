@@ -514,8 +514,8 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     /* A frame is traced as BANDS of whole 8-row tiles.  Frames above `band_pixels` need them so that the queue and node buffers stay
      * bounded (a band of 4 Mpixel needs ~25 GB at depth 16; an 8K frame goes through in 8 passes); smaller frames are cut into
      * `wf_n_streams` bands that run as independent pipelines on streams of their own, so that one band's dependent launches -- each
-     * ending in a tail during which most of the chip idles -- are covered by the other bands' kernels.  Every band launches a share
-     * of a full-chip grid (`band_grid_permille`): together the bands oversubscribe the chip, which is what fills the tails. */
+     * ending in a tail during which most of the chip idles -- are covered by the other bands' kernels.  Every band launches full-chip
+     * grids (`band_grid_permille` can shrink them): together the bands oversubscribe the chip, which is what fills the tails. */
     uint32_t band_rows = df_in.local_rows;
     int n_par = 1;                  /* band pipelines in flight */
     if (!df_in.single_pixel) {
@@ -546,7 +546,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
     const size_t band_items = df_in.single_pixel ? 64 : (size_t)df_in.tiles_x * ((band_rows + 7) / 8) * 64;      /* generation 0: one slot per item of the band's 8x8 tiles */
     /* the share of a full-chip grid one band pipeline launches */
     uint32_t permille = 1000;
-    if (side_streams) permille = r->opts.band_grid_permille ? r->opts.band_grid_permille : (uint32_t)(2000 / n_par < 250 ? 250 : (2000 / n_par > 1000 ? 1000 : 2000 / n_par));
+    if (side_streams && r->opts.band_grid_permille) permille = r->opts.band_grid_permille;      /* (default: every band launches full-chip grids -- measured, 3 bands of 3d_room: 1000 / 667 = 1.37 / 1.39 ms) */
     if (permille > 1000) permille = 1000;
     int rc = wf_ensure(r, df_in.single_pixel ? 64 : band_pixels, band_items, dc.max_depth, n_par, df_in.single_pixel ? 0u : permille);
     if (rc != EU_OK) return rc;
@@ -971,6 +971,7 @@ struct eu_sequence {
      * until the NEXT eu_sequence_next, however many frames are submitted in between */
     std::vector<uint8_t *> host_rgb;
     unsigned long long submitted = 0, taken = 0;
+    int saved_streams = 0;                   /* the renderer's own band pipelines per frame, put back when the sequence goes */
 };
 
 extern "C" void eu_sequence_destroy(eu_sequence *q) {
@@ -990,6 +991,7 @@ extern "C" void eu_sequence_destroy(eu_sequence *q) {
     for (hipStream_t st : q->slot_stream) if (st) (void)hipStreamDestroy(st);
     if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     for (size_t k = 1; k < q->slot_renderer.size(); k++) eu_renderer_destroy(q->slot_renderer[k]);
+    if (q->r && q->saved_streams) q->r->wf_n_streams = q->saved_streams;
     delete q;
 }
 
@@ -1007,6 +1009,10 @@ extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t m
     q->slot_renderer.assign(slots, nullptr);
     q->slot_stream.assign(slots, nullptr);
     q->slot_renderer[0] = r;
+    /* with several frames in flight it is the FRAMES that cover each other's kernel tails: every slot traces its frame as one band
+     * (unless the caller chose a number), the launches stay large */
+    const bool one_band = slots > 1 && r->opts.streams == 0;
+    if (one_band) { q->saved_streams = r->wf_n_streams; r->wf_n_streams = 1; }
     for (uint32_t k = 0; k < slots; k++) {
         if ((e = hipStreamCreateWithFlags(&q->slot_stream[k], hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
         if (k > 0) {
@@ -1015,6 +1021,7 @@ extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t m
             o.struct_size = sizeof o;
             o.cache_dir = r->cache_dir.empty() ? nullptr : r->cache_dir.c_str();
             o.jit_flags = r->jit_flags.empty() ? nullptr : r->jit_flags.c_str();
+            if (one_band) o.streams = 1;
             const int crc = renderer_create_impl(r->flat, r->device, &o, &q->slot_renderer[k], cerr, sizeof cerr);      /* (a specialised renderer's clones find its code object in the in-process cache) */
             if (crc != EU_OK) { r->err = std::string("frame sequence slot: ") + cerr; q->slot_renderer.resize(k); eu_sequence_destroy(q); return crc; }
         }

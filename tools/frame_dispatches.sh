@@ -3,7 +3,7 @@
 # previous dispatch's end (rocprofv3 --kernel-trace).  Usage: BENCH_ARGS="--streams 1" tools/frame_dispatches.sh <tag>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/disp_$tag -o k -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline $BENCH_ARGS > gpurun_out/disp_$tag.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/disp_$tag -o k -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --repeats 1 --no-alone $BENCH_ARGS > gpurun_out/disp_$tag.log 2>&1 || exit 1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/disp_%s/**/*kernel_trace.csv" % sys.argv[1], recursive=True)

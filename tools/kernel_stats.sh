@@ -2,7 +2,7 @@
 # rocprofv3 per-kernel statistics of bench.py (run on the GPU box from the repo root).  Usage: BENCH_ARGS="--streams 1" tools/kernel_stats.sh <tag>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o k -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --repeats 1 --no-alone --no-other-configs $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1 || exit 1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/prof_%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True)

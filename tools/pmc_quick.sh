@@ -3,7 +3,7 @@
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pq_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --streams 1 --frames-in-flight 1 ${BENCH_ARGS:-} > $R/gpurun_out/pq_$tag.log 2>&1 || { echo "rc=$?"; tail -5 $R/gpurun_out/pq_$tag.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pq_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --repeats 1 --no-alone --no-other-configs --streams 1 --frames-in-flight 1 ${BENCH_ARGS:-} > $R/gpurun_out/pq_$tag.log 2>&1 || { echo "rc=$?"; tail -5 $R/gpurun_out/pq_$tag.log; exit 1; }
 python3 - "$R/gpurun_out/pq_$tag" <<'PY'
 import csv, glob, sys, collections
 v = collections.defaultdict(lambda: collections.defaultdict(list))
