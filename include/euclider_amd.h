@@ -188,10 +188,12 @@ int eu_renderer_stats(eu_renderer *, eu_stats *);
 int eu_renderer_kernel_ms(eu_renderer *, float *ms);
 /* The same for the most recent min(max_n, 64) launches, oldest first; returns how many were written. */
 int eu_renderer_kernel_ms_history(eu_renderer *, float *ms, int max_n);
-/* Number of frames eu_render / eu_render_multi had to trace a second time since the renderer was created: a frame whose
- * recursion fans out beyond the ray queues (more than eu_renderer_opts.ray_factor rays per pixel in one generation) is traced
- * again by the stack-based kernel, several times slower.  The result is the same either way; this counter is how a caller
- * notices the slow path (the asynchronous calls do not retry, they report EU_ERR_CAPACITY). */
+/* Number of frames (or single pixels) eu_render / eu_trace_screen_point / eu_sequence_next / eu_render_multi had to trace a second
+ * time since the renderer was created: a frame whose recursion fans out beyond the ray queues (more than eu_renderer_opts.ray_factor
+ * rays per pixel in one generation), or one of whose rays needed more hit-stack entries than the wavefront kernels reserve, is
+ * traced again by the stack-based kernel, several times slower.  The result is the same either way; this counter is how a caller
+ * notices the slow path.  Only the plainly asynchronous eu_render_device cannot retry: eu_renderer_stats then returns
+ * EU_ERR_CAPACITY and eu_renderer_error says which of the two it was. */
 int eu_renderer_retraces(eu_renderer *, uint64_t *count);
 
 /* Diagnostic builds (-DEU_PROFILE_PHASES) only: summed per-wave cycle shares of the kernel's phases
@@ -207,14 +209,16 @@ int eu_renderer_debug_generations(eu_renderer *, unsigned long long out[17]);
  * recursion fans out beyond the wavefront queues (reported as EU_ERR_CAPACITY by eu_renderer_stats after the asynchronous
  * eu_render_device), this call traces it again with the stack-based persistent kernel, which has no such limit. */
 int eu_render(eu_renderer *, const eu_camera *, const eu_frame *, uint8_t *rgb_host, double *hit_t_host, eu_stats *);
-/* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F>. */
+/* Environment::trace_screen_point (universe/mod.rs:371-397): one pixel, un-quantised Rgb<F> (traced again by the stack-based kernel should
+ * the wavefront pipeline have dropped one of its rays). */
 int eu_trace_screen_point(eu_renderer *, const eu_camera *, const eu_frame *, int32_t x, int32_t y, double rgb[3]);
 
 /* ---- frame sequences ("next" row f4 of the scope table) ---------------------------------------------
  * The frame loop around Environment::render (simulation.rs:93-150): the reference finishes a frame, uploads it and only
  * then starts the next.  A sequence keeps up to `slots` frames in flight on its own streams: eu_sequence_submit queues
  * trace + RGB8 pack + an asynchronous copy into pinned host memory and returns at once; eu_sequence_next waits for the
- * OLDEST submitted frame and hands out its image (rows of the reference's RawImage2d; the sequence owns slots + 1
+ * OLDEST submitted frame (tracing it again with the stack-based kernel, synchronously, should the wavefront pipeline have dropped
+ * rays: eu_renderer_retraces) and hands out its image (rows of the reference's RawImage2d; the sequence owns slots + 1
  * pinned images, so the one handed out stays valid until the NEXT eu_sequence_next, however many frames are submitted in
  * between) and its counters.  Frames may differ in size (the run-time `resolution` divisor, simulation.rs:284-306), time
  * (time-varying surfaces) and camera.  Every slot traces on its own stream with its own work buffers and counters (the scene

@@ -14,6 +14,19 @@ from euclider_amd import Parser  # noqa: E402
 scene, depth, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 dev = torch.device("cuda", 0)
 print("GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES", "(unset: 4)"))
+# EU_SWEEP_DUMMIES=n: n other renderers (one band each, a frame traced on a torch stream of its own) stay alive during the sweep -- how a
+# process full of streams changes what a renderer's band streams get from the runtime's hardware queues
+dummies = []
+for k in range(int(os.environ.get("EU_SWEEP_DUMMIES", "0"))):
+    e = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize="sync", streams=1)
+    e.camera.max_depth = depth
+    st_k = torch.cuda.Stream(dev)
+    buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    e.render_device(e.frame(W, H, time=0.0, rows=(0, H)), buf.data_ptr(), None, st_k.cuda_stream, device=0)
+    dummies.append((e, st_k, buf))
+torch.cuda.synchronize()
+if dummies:
+    print("dummy renderers alive:", len(dummies))
 for spec in sys.argv[5:]:
     parts = spec.split(":")
     streams, permille = int(parts[0]), int(parts[1])
