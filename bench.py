@@ -180,36 +180,24 @@ F64_PEAK_TFLOPS = 78.6
 
 def valu_figure(workload_key, kernel_ms):
     """Secondary roofline (the path is f64-VALU bound, not HBM bound): wave-level VALU instructions of one frame
-    pipeline (PMC, committed) over the live kernel time, against the VALU issue peak.  The peak is weighted with the kernels'
-    instruction mix: cycles per instruction = 4 for the f64 share, 2 for the rest (static mix of each kernel, profiles/
-    r02_isa_mix.json, weighted with each kernel's dynamic VALU count, profiles/r02_room_pmc.json: a mix measured on 3d_room's
-    round-2 kernels, labelled as such in `mix`)."""
-    pmc = load_pmc(workload_key)
-    n = pmc.get("valu_wave_insts_per_launch")
-    if not n:
-        return None
-    cycles = 4.0
-    mix_src = "every VALU instruction priced at 4 cycles (no mix on file)"
+    pipeline over the kernel time, against the VALU issue peak.  Everything comes from THIS round's profiles of the kernels that
+    ran (profiles/r04_isa_mix.json, made by tools/isa_mix_r04.py from profiles/r04_<workload>_pmc.json and the disassembly of the
+    specialised code objects): the instruction count per frame is the PMC passes' SQ_INSTS_VALU x launches per frame, and the peak
+    is priced with the same kernels' instruction mix -- 4 SIMD cycles for an f64 VALU instruction, 2 for any other, each kernel's
+    static f64 share weighted with its dynamic VALU count.  A workload without such a profile gets no figure."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))["kernels"]
-        dyn = json.load(open(os.path.join(ROOT, "profiles", "r02_room_pmc.json")))
-        num = den = 0.0
-        for k, d in dyn["derived"].items():
-            short = k.split("<")[0]
-            if short in mix and "SQ_INSTS_VALU_per_launch" in d:
-                w = d["SQ_INSTS_VALU_per_launch"] * dyn["launches_per_frame_single_stream"].get(k, 1)
-                f = mix[short]["valu_f64_share"]
-                num += w * (4.0 * f + 2.0 * (1.0 - f))
-                den += w
-        if den:
-            cycles = num / den
-            mix_src = "3d_room round-2 kernels: profiles/r02_isa_mix.json x profiles/r02_room_pmc.json"
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_mix.json")))["workloads"].get(workload_key)
     except Exception:
-        pass
+        rec = None
+    if not rec or "cycles_per_valu_instruction" not in rec:
+        return None
+    n = rec["valu_wave_insts_per_frame"]
+    cycles = rec["cycles_per_valu_instruction"]
     peak = SIMD_CYCLES_PER_S / cycles / 1e9
     ach = n / (kernel_ms * 1e-3) / 1e9
     return {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak, "cycles_per_instruction": cycles,
-            "mix": mix_src, "lane_utilisation": pmc.get("valu_lane_utilisation"), "wave_insts_per_launch": n}
+            "mix": "profiles/r04_isa_mix.json (this round's specialised kernels: static f64 share per kernel x dynamic VALU count per kernel)",
+            "lane_utilisation": load_pmc(workload_key).get("valu_lane_utilisation"), "wave_insts_per_launch": n}
 
 
 def flops_figure(workload_key, rays, kernel_ms):
@@ -388,6 +376,7 @@ def other_configs(torch, dev, Parser, args, in_flight):
                     "would_panic_events": int(st["nan_pixels"] + st["errors"]),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "kernel_ms": kernel_ms, "algorithmic_bytes": alg, "traffic": None if lp else load_traffic("%s %dx%d depth %d" % (scene, W, H, depth)),
+                                 "valu": None if lp else valu_figure("%s %dx%d depth %d" % (scene, W, H, depth), kernel_ms),
                                  "flops": None if lp else flops_figure("%s %dx%d depth %d" % (scene, W, H, depth), st["rays"], kernel_ms)},
                     "specialized": env.jit_info(device=dev.index)["active"]})
         for e in envs:

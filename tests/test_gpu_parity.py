@@ -420,7 +420,7 @@ def test_pipeline_forms_agree(scene, depth, W, H):
              dict(streams=1, flags=_capi.EU_RENDERER_NO_FUSE), dict(streams=3, split_pixels=4096, flags=_capi.EU_RENDERER_NO_FUSE),
              dict(streams=2, split_pixels=4096, band_grid_permille=400)]
     from euclider_amd import environment
-    if environment.DEFAULT_RENDERER_OPTS.get("specialize") == "sync":      # the tuning flags reach the specialised kernels only
+    if environment.DEFAULT_RENDERER_OPTS.get("specialize") == "sync" and scene in ("3d_room.json", "4d_frame.json"):      # the tuning flags reach the specialised kernels only (a compilation each)
         forms += [dict(streams=2, split_pixels=4096, jit_flags="-DEU_WF_SPREAD=1"), dict(streams=1, jit_flags="-DEU_WF_DEAL_ISECT=1 -DEU_WF_DEAL_SHADE=1 -DEU_WF_WIN_MIN=256"),
                   dict(streams=2, split_pixels=4096, flags=_capi.EU_RENDERER_NO_FUSE, jit_flags="-DEU_WF_DEAL_ISECT=1 -DEU_WF_DEAL_SHADE=1 -DEU_WF_WIN=512"),
                   dict(streams=1, jit_flags="-DEU_WF_EQUAL_WIN=0 -DEU_SHADE_TAKE_CHUNKS=0")]
