@@ -642,9 +642,9 @@ def main():
                        "partition": ("%d ranks, 8-row strips round-robin, 1 RCCL gather" % world) if world > 1 else "1 GPU, whole frame",
                        "background": "procedural 1024x512 UV grid (reference's universe_dim.jpg is not shipped)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(workload), "kernel": "%s frame pipeline (%dx intersect+shade, %dx resolve)" % ("eu_jit_* + eu_wf_resolve" if jit["active"] else "eu_wf_*", args.max_depth, args.max_depth), "kernel_ms": kernel_ms,
+                         "traffic": load_traffic(workload), "kernel": "%s frame pipeline (generation-0 intersect, %d fused shade+intersect launches, %d resolve launches)" % ("eu_jit_intersect0 + eu_jit_fshade0/fshade + eu_wf_resolve" if jit["active"] else "eu_wf_*", args.max_depth, args.max_depth), "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms), "flops": flops_figure(workload, rays_per_step, kernel_ms),
-                         "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it"},
+                         "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it; traffic / valu: profiles/r04_*_pmc.json, profiles/r04_isa_mix.json"},
         }
         if cfg5 is not None:
             out["config5"] = cfg5
