@@ -550,6 +550,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
 #endif
     const uint32_t in = gen & 1u, outb = (gen + 1) & 1u;
     const uint32_t child_depth = max_depth - gen - 1;
+    const bool last_gen = child_depth == 0;
     const uint32_t out_base = blockIdx.x * B.seg_cap;
     const uint32_t node_base = gen * B.ray_cap;       /* node id of queue slot q: node_base + q */
     __shared__ uint32_t pref[EU_WF_MAX_SEG + 1];
@@ -651,6 +652,10 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
             const uint32_t nid = node_base + i;
             /* children of this ray: 0 = transmission, 1 = reflection; c_sm = slot | delivery mode << 1 (trace_nodes.h) */
             uint32_t n_child = 0;
+            uint32_t fin_kind = TS_NONE, fin_parent = 0, fin_sm = 0;      /* last generation: the node this lane finishes itself */
+            real fin_ratio = R(0.0);
+            uint32_t fin_spx = 0;
+            Rgba fin_inter = {R(0.0), R(0.0), R(0.0), R(0.0)};
             real c_o[2][D], c_d[2][D];
             uint32_t c_ent[2] = {0, 0}, c_parent[2] = {0, 0}, c_sm[2] = {0, 0};
             bool bg_miss = false;
@@ -731,11 +736,16 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                             if (rs) { c_d[1][k] = rd; c_o[1][k] = ro; } else { c_d[0][k] = rd; c_o[0][k] = ro; }
                         }
                     }
+                    fin_ratio = ratio; fin_spx = spx; fin_inter = inter;
                     EuTsNode *N = B.nodes + nid;
+                    /* (the last generation -- no depth left -- queues nothing: its children are background samples this very thread takes,
+                     * so it finishes the node in registers, below, and no record is written) */
                     if (need_trans) {      /* the transmitted colour arrives quantised (slot 0), the reflection as it is (slot 1) */
                         node_kind = need_refl ? TS_COMBINE_TRANS : TS_OVER;
+                        if (!last_gen) {
                         N->spx = spx; N->parent = parent; N->meta = node_kind | (sm << 8);
                         if (need_refl) N->ratio = ratio;
+                        }
                         c_ent[0] = (uint32_t)dest; c_parent[0] = nid; c_sm[0] = 0u | (TS_MODE_U8 << 1);
                         n_child = 1;
                         if (need_refl) { c_ent[1] = ent; c_parent[1] = nid; c_sm[1] = 1u | (TS_MODE_F64 << 1); n_child = 2; }
@@ -744,8 +754,10 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                         n_child = 1;
                         if (have_inter) {      /* the opaque surface colour waits in the node; the reflection is combined with it on arrival */
                             node_kind = TS_COMBINE_INTER;
+                            if (!last_gen) {
                             N->ratio = ratio; N->parent = parent; N->meta = node_kind | (sm << 8);
                             N->c1[0] = inter.r; N->c1[1] = inter.g; N->c1[2] = inter.b; N->c1[3] = inter.a;
+                            }
                             c_parent[0] = nid; c_sm[0] = 1u | (TS_MODE_INTER << 1);
                         } else {   /* the reflection colour is the result (surface.rs:153-154): the child reports to our parent */
                             c_parent[0] = parent; c_sm[0] = sm;
@@ -755,7 +767,8 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                         ts_deliver(B.nodes, parent, sm, inter, cnt, rgba, point_rgb);
                     }
                 }
-                B.node_kind[nid] = (uint8_t)(node_kind == TS_COMBINE_TRANS ? TS_COMBINE_TRANS : TS_NONE);      /* (only a node with two children is left to the resolve pass: trace_nodes.h) */
+                B.node_kind[nid] = (uint8_t)(node_kind == TS_COMBINE_TRANS && !last_gen ? TS_COMBINE_TRANS : TS_NONE);      /* (only a node with two children is left to the resolve pass: trace_nodes.h) */
+                fin_kind = node_kind; fin_parent = parent; fin_sm = sm;
             }
             /* children with no depth left (or plain misses) only sample the background
              * (universe/mod.rs:157,183): one code site for all of them */
@@ -763,13 +776,30 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
             /* (a lane's children are either all background-only or all queued: the miss case has one child) */
             const bool bg_only = n_child != 0 && (bg_miss || child_depth == 0);
             const uint32_t n_queue = bg_only ? 0u : n_child;
+            Rgba bgc[2] = {{R(0.0), R(0.0), R(0.0), R(0.0)}, {R(0.0), R(0.0), R(0.0), R(0.0)}};
 #pragma unroll 1
             for (uint32_t k = 0; k < 2; k++) {      /* constant indices only: a run-time indexed private array would live in scratch */
                 if (bg_only && k < n_child) {
                     real dd[D];
 #pragma unroll
                     for (int q = 0; q < D; q++) dd[q] = k ? c_d[1][q] : c_d[0][q];
-                    ts_deliver(B.nodes, k ? c_parent[1] : c_parent[0], k ? c_sm[1] : c_sm[0], ts_background<D, P>(S, dd, cnt), cnt, rgba, point_rgb);
+                    const Rgba bg = ts_background<D, P>(S, dd, cnt);
+                    if (k) bgc[1] = bg; else bgc[0] = bg;
+                }
+            }
+            if (bg_only) {
+                if (bg_miss || fin_kind == TS_NONE) {      /* a ray that hit nothing, or a reflection that IS the result (surface.rs:153-154): the colour goes where the ray's would */
+                    ts_deliver(B.nodes, c_parent[0], c_sm[0], bgc[0], cnt, rgba, point_rgb);
+                } else {
+                    /* the node's children are both here: what ts_deliver and the resolve pass would do with its record, done in registers
+                     * (surface.rs:104-114: surface_palette.over(transition_palette), both quantised; :159-161: combine_palette_color) */
+                    Rgba res;
+                    if (fin_kind == TS_COMBINE_INTER) res = combine_palette_color(bgc[0], fin_inter, fin_ratio);
+                    else {
+                        const Rgba over = blend_rgba(EU_BL_OVER, new_u8(fin_spx), new_u8(to_pixel4(bgc[0], cnt)));
+                        res = fin_kind == TS_OVER ? over : combine_palette_color(bgc[1], over, fin_ratio);
+                    }
+                    ts_deliver(B.nodes, fin_parent, fin_sm, res, cnt, rgba, point_rgb);
                 }
             }
             WF_STAMP(6);

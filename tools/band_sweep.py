@@ -32,7 +32,7 @@ for spec in sys.argv[5:]:
     streams, permille = int(parts[0]), int(parts[1])
     flags = (parts[2].replace(",", " ") or None) if len(parts) > 2 else None
     rflags = int(parts[3]) if len(parts) > 3 else 0
-    env = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize="sync", streams=streams, band_grid_permille=permille, jit_flags=flags, flags=rflags)
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize=os.environ.get("EU_SWEEP_SPECIALIZE", "sync"), streams=streams, band_grid_permille=permille, jit_flags=flags, flags=rflags)
     env.camera.max_depth = depth
     img = env.render((W, H))
     rgba = torch.zeros((H, W), dtype=torch.int32, device=dev)
