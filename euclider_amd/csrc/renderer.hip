@@ -131,6 +131,9 @@ struct eu_renderer {
     uint32_t wf_seg_per_cu = 3;              /* producer (shade) workgroups per CU = queue segments per CU: 3 for the interpreter's shade kernel (168 VGPRs),
                                               * what the specialised one's registers allow (up to 4) */
     int wf_n_streams = 2;
+    bool wf_streams_auto = true;             /* no number from the caller: one band or three, by how many rays per pixel the frames turn out to have */
+    unsigned long long *h_rays_sample = nullptr;      /* pinned: the ray count of a recent frame, copied behind its launches every few frames */
+    uint64_t sample_pixels = 0;
     real wf_ray_factor = R(4.0);
     uint64_t wf_band_pixels = 4u << 20;      /* pixels traced per wavefront pass */
     uint64_t wf_split_pixels = 1u << 19;     /* frames of at least this many pixels are cut into wf_n_streams concurrent bands */
@@ -320,6 +323,7 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
          * 1.36 / 1.28 / 1.87 ms; 8K: 2 / 3 = 16.4 / 15.1 ms); one for the others, whose frames are chains of small launches (3d_hallways
          * 0.56 / 0.54 / 0.54 ms, 4d_cylinders 0.45 / 0.46 / 0.51) */
         r->wf_n_streams = r->opts.streams ? (int)r->opts.streams : ((h.flags & 1u) ? 3 : 1);
+        r->wf_streams_auto = r->opts.streams == 0;
         if (r->opts.ray_factor > 0.0) r->wf_ray_factor = (real)r->opts.ray_factor;
         if (r->opts.band_pixels) r->wf_band_pixels = r->opts.band_pixels;
         if (r->opts.split_pixels) r->wf_split_pixels = r->opts.split_pixels;
@@ -338,6 +342,8 @@ static int renderer_create_impl(std::shared_ptr<const euclider::FlatScene> flat_
         HIP_TRY(hipMemset(r->d_counters, 0, eu_renderer::counters_bytes(eu_renderer::WF_MAX_STREAMS)));
         HIP_TRY(hipDeviceSynchronize());      /* (hipMemset is asynchronous to the host; see wf_ensure) */
         HIP_TRY(hipMalloc((void **)&r->d_point, 3 * sizeof(eu_f64)));
+        HIP_TRY(hipHostMalloc((void **)&r->h_rays_sample, 16, hipHostMallocDefault));
+        r->h_rays_sample[0] = 0ull; r->h_rays_sample[1] = 0ull;
         for (int i = 0; i < eu_renderer::EV_RING; i++) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
         if ((specialize == EU_SPECIALIZE_SYNC || specialize == EU_SPECIALIZE_ASYNC) && r->use_wavefront) renderer_attach_jit(r, specialize == EU_SPECIALIZE_ASYNC);
         if (r->use_wavefront && !r->jit_intersect0) { if (r->dim == 3) interp_seg_per_cu<3>(r); else interp_seg_per_cu<4>(r); }
@@ -383,6 +389,7 @@ extern "C" void eu_renderer_destroy(eu_renderer *r) {
     if (r->d_hit) (void)hipFree(r->d_hit);
     if (r->d_point) (void)hipFree(r->d_point);
     if (r->d_prof) (void)hipFree(r->d_prof);
+    if (r->h_rays_sample) (void)hipHostFree(r->h_rays_sample);
     if (r->d_path_in) (void)hipFree(r->d_path_in);
     if (r->d_path_out) (void)hipFree(r->d_path_out);
     for (int i = 0; i < eu_renderer::EV_RING; i++) { if (r->ev_start[i]) (void)hipEventDestroy(r->ev_start[i]); if (r->ev_stop[i]) (void)hipEventDestroy(r->ev_stop[i]); }
@@ -719,6 +726,17 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
         if (r->use_wavefront) return (r->dim == 3) ? wf_launch_frame<3>(r, stream, dc, df, rgba, hit_t, point) : wf_launch_frame<4>(r, stream, dc, df, rgba, hit_t, point);
         return EU_OK;
     }
+    /* The scene's flag says whether its recursion CAN branch; whether it does shows in the frames: 4d_cylinders' surfaces reflect (ratio 0.2)
+     * but are opaque, its frames hold one ray per pixel, and three band pipelines cost it 12 % (0.51 against 0.45 ms).  Every few frames the
+     * ray count is copied to pinned memory behind the frame's launches; a renderer whose caller named no number of bands reads what has
+     * arrived so far -- never waiting -- and takes three bands above 2.5 rays per pixel, one below 1.6. */
+    if (r->use_wavefront && r->wf_streams_auto && !single && r->sample_pixels) {
+        const double rpp = (double)r->h_rays_sample[0] / (double)r->sample_pixels;
+        if (r->h_rays_sample[0] != 0ull) {
+            if (rpp > 2.5) r->wf_n_streams = 3;
+            else if (rpp < 1.6) r->wf_n_streams = 1;
+        }
+    }
     {
         const uint32_t nb = r->use_wavefront ? (uint32_t)(r->wf_n_streams > 1 ? r->wf_n_streams : 1) : 0u;
         const uint32_t ng = (cam->max_depth ? cam->max_depth : 1u) + 1u;
@@ -745,6 +763,10 @@ static int render_device_impl(eu_renderer *r, const eu_camera *cam, const eu_fra
     }
     if (e != hipSuccess) { r->err = std::string("kernel launch: ") + hipGetErrorString(e); return EU_ERR_HIP; }
     HIP_TRY(hipEventRecord(r->ev_stop[slot], stream));
+    if (r->use_wavefront && r->wf_streams_auto && !single && (r->launches < 2 || r->launches % 8 == 0)) {
+        HIP_TRY(hipMemcpyAsync(r->h_rays_sample, &r->d_counters->rays, 8, hipMemcpyDeviceToHost, stream));
+        r->sample_pixels = (uint64_t)rows * f->width;
+    }
     r->launches++;
     r->last_stream = stream;
     return EU_OK;
@@ -991,7 +1013,7 @@ extern "C" void eu_sequence_destroy(eu_sequence *q) {
     for (hipStream_t st : q->slot_stream) if (st) (void)hipStreamDestroy(st);
     if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     for (size_t k = 1; k < q->slot_renderer.size(); k++) eu_renderer_destroy(q->slot_renderer[k]);
-    if (q->r && q->saved_streams) q->r->wf_n_streams = q->saved_streams;
+    if (q->r && q->saved_streams) { q->r->wf_n_streams = q->saved_streams; q->r->wf_streams_auto = q->r->opts.streams == 0; }
     delete q;
 }
 
@@ -1012,7 +1034,7 @@ extern "C" int eu_sequence_create(eu_renderer *r, uint32_t max_width, uint32_t m
     /* with several frames in flight it is the FRAMES that cover each other's kernel tails: every slot traces its frame as one band
      * (unless the caller chose a number), the launches stay large */
     const bool one_band = slots > 1 && r->opts.streams == 0;
-    if (one_band) { q->saved_streams = r->wf_n_streams; r->wf_n_streams = 1; }
+    if (one_band) { q->saved_streams = r->wf_n_streams; r->wf_n_streams = 1; r->wf_streams_auto = false; }
     for (uint32_t k = 0; k < slots; k++) {
         if ((e = hipStreamCreateWithFlags(&q->slot_stream[k], hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
         if (k > 0) {

@@ -446,3 +446,19 @@ def test_renderer_error_text():
     assert L.eu_render(r, C.byref(cam), C.byref(fr), out.ctypes.data, None, None) == _capi.EU_ERR_INVALID_ARGUMENT
     assert b"dimension" in L.eu_renderer_error(r)
     env.close()
+
+
+def test_band_count_follows_the_frames():
+    """A renderer whose caller named no number of bands starts from the scene's flag (4d_cylinders' surfaces reflect: three bands) and
+    then goes by the rays per pixel its frames turn out to have (one ray per pixel: one band from the third frame on) -- the switch, the
+    buffers cut anew and every frame on either side of it give the oracle's picture."""
+    from euclider_amd import Parser
+    from oracle.scene_loader import load_scene_file
+    path = os.path.join(SCENES, "4d_cylinders.json")
+    orgb, _, ost = load_scene_file(path).render(1024, 576, max_depth=4)
+    env = Parser().parse_file(path)
+    env.camera.max_depth = 4
+    for k in range(5):
+        img = env.render((1024, 576))
+        assert np.array_equal(img.data, orgb) and img.stats["rays"] == ost["rays"], k
+    env.close()
