@@ -139,7 +139,8 @@ typedef struct {
     uint32_t struct_size;        /* sizeof(eu_renderer_opts) of the caller: the struct may grow */
     uint32_t kernel;             /* EU_KERNEL_* */
     uint32_t specialize;         /* EU_SPECIALIZE_* */
-    uint32_t streams;            /* band pipelines in flight per frame, 1..8 (0: the library's choice) */
+    uint32_t streams;            /* band pipelines in flight per frame, 1..8 (0: the library's choice -- three for a scene whose recursion can branch, else one;
+                                    after the first frames it goes by their rays per pixel: three above 2.5, one below 1.6) */
     double ray_factor;           /* ray-queue slots per pixel and generation (0: 4.0); a frame that needs more is reported through
                                     EU_ERR_CAPACITY (asynchronous calls) or traced again by the stack kernel (eu_render, eu_render_multi) */
     uint64_t band_pixels;        /* pixels per wavefront pass (0: 4 Mi): larger frames are traced in bands of whole 8-row tiles */
