@@ -99,6 +99,7 @@ SYMBOLS = {
     "eu_renderer_destroy": (None, [C.c_void_p]),
     "eu_renderer_jit_info": (C.c_int, [C.c_void_p, C.POINTER(JitInfo)]),
     "eu_renderer_error": (C.c_char_p, [C.c_void_p]),
+    "eu_renderer_jit_log": (C.c_char_p, [C.c_void_p]),
     "eu_scene_jit_source": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]),
     "eu_scene_jit_precompile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(JitInfo), C.c_char_p, C.c_size_t]),
     "eu_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,

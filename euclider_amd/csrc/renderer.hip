@@ -365,6 +365,7 @@ extern "C" int eu_renderer_create(const eu_scene *scene, int device, eu_renderer
 }
 
 extern "C" const char *eu_renderer_error(const eu_renderer *r) { return r ? r->err.c_str() : ""; }
+extern "C" const char *eu_renderer_jit_log(const eu_renderer *r) { return r ? r->jit_log.c_str() : ""; }
 
 extern "C" int eu_renderer_jit_info(eu_renderer *r, eu_jit_info *out) {
     if (!r || !out) return EU_ERR_INVALID_ARGUMENT;

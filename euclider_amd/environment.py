@@ -148,7 +148,8 @@ class Environment:
         if rc != _capi.EU_OK:
             raise EuError(rc)
         return {"requested": bool(info.requested), "active": bool(info.active), "from_cache": bool(info.from_cache),
-                "hit_stack_entries": info.hit_stack_entries, "compile_ms": info.compile_ms, "key": info.key.decode()}
+                "hit_stack_entries": info.hit_stack_entries, "compile_ms": info.compile_ms, "key": info.key.decode(),
+                "log": (self._L.eu_renderer_jit_log(self.renderer(device)) or b"").decode(errors="replace")}
 
     def jit_source(self):
         """The HIP source of this scene's specialised kernels (no GPU needed)."""

@@ -169,6 +169,9 @@ void eu_renderer_destroy(eu_renderer *);
 int eu_renderer_jit_info(eu_renderer *, eu_jit_info *out);
 /* What the most recent failing call on this renderer had to say (valid until the next call on it; "" if nothing failed yet). */
 const char *eu_renderer_error(const eu_renderer *);
+/* Why a renderer that was asked to specialise runs the interpreter kernels (eu_jit_info.active == 0): the scene is beyond the generator's
+ * limits (more than 256 shape operations or 48 entities), or the compiler's log; "" when the specialised kernels are in use. */
+const char *eu_renderer_jit_log(const eu_renderer *);
 /* The HIP source eu_renderer_create_opts(EU_SPECIALIZE_SYNC) would compile for this scene (no GPU needed): *source is allocated
  * with eu_alloc, NUL-terminated; free it with eu_free.  key (optional, >= 40 bytes): the cache key. */
 int eu_scene_jit_source(const eu_scene *, char **source, char *key);

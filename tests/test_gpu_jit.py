@@ -45,6 +45,7 @@ def test_failed_compilation_falls_back_to_the_interpreter(tmp_path):
     info = bad.jit_info()
     bad.close()
     assert info["requested"] and not info["active"]
+    assert "error" in info["log"].lower()          # eu_renderer_jit_log: why the interpreter kernels are in charge (the compiler's words)
     assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
 
 
