@@ -67,9 +67,6 @@
 #ifndef EU_WF_WIN_MIN
 #define EU_WF_WIN_MIN 512u
 #endif
-#ifndef EU_SHADE_FAST_PREP
-#define EU_SHADE_FAST_PREP 1      /* shade window: key counts scanned by half a wave, queue slots of a thread's later rays found by a short walk */
-#endif
 #ifndef EU_WF_EQUAL_WIN
 #define EU_WF_EQUAL_WIN 1
 #endif
@@ -221,23 +218,6 @@ EU_DEV uint32_t wf_map_index(const uint32_t *pref, uint32_t n_seg, uint32_t seg_
 #pragma unroll
     for (uint32_t step = EU_WF_MAX_SEG / 2; step != 0; step >>= 1) lo += pref[lo + step] <= v ? step : 0u;
     return lo * seg_cap + (v - pref[lo]);
-}
-
-/* the same for a ray number at or behind one whose segment is known (a thread's slots of a shade window lie 256 rays apart: the next one
- * is in the same segment or a few further on): a short walk instead of ten dependent LDS reads; many empty segments in between: the search */
-EU_DEV uint32_t wf_map_index_from(const uint32_t *pref, uint32_t n_seg, uint32_t seg_cap, uint32_t v, uint32_t &seg) {
-    uint32_t s = seg;
-    if (s < EU_WF_MAX_SEG) {      /* (EU_WF_MAX_SEG: no segment known yet) */
-#pragma unroll
-        for (int step = 0; step < 4; step++) if (pref[s + 1] <= v) s++;      /* (pref[n_seg] = total > v and sentinels behind it: the walk cannot run away) */
-    }
-    if (s >= EU_WF_MAX_SEG || pref[s + 1] <= v) {
-        s = 0;
-#pragma unroll
-        for (uint32_t step = EU_WF_MAX_SEG / 2; step != 0; step >>= 1) s += pref[s + step] <= v ? step : 0u;
-    }
-    seg = s;
-    return s * seg_cap + (v - pref[s]);
 }
 
 /* ------------------------------------------------------------------ dealing 64-ray batches to waves (intersect kernel)
@@ -620,7 +600,6 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
             if (threadIdx.x < EU_WF_KEYS) hist[threadIdx.x] = 0;
             __syncthreads();
             uint32_t myq[EU_WF_WIN / EU_WF_BLOCK], mykey[EU_WF_WIN / EU_WF_BLOCK], myrank[EU_WF_WIN / EU_WF_BLOCK];
-            uint32_t seg_walk = 0;
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) {
                 const uint32_t kb = k * EU_WF_BLOCK;
@@ -631,13 +610,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
 #endif
                 mykey[k] = 0xffffffffu; myq[k] = 0; myrank[k] = 0;
                 if (kb < win && v < total) {
-#if EU_WF_SPREAD || !EU_SHADE_FAST_PREP
                     myq[k] = g0 ? v : wf_map_index(pref, B.n_seg, B.seg_cap, v);
-#else
-                    if (g0) myq[k] = v;
-                    else if (k == 0) { seg_walk = EU_WF_MAX_SEG; myq[k] = wf_map_index_from(pref, B.n_seg, B.seg_cap, v, seg_walk); }
-                    else myq[k] = wf_map_index_from(pref, B.n_seg, B.seg_cap, v, seg_walk);
-#endif
                     const uint32_t he = B.hit[in][myq[k]].ent;
                     if (he == EU_WF_ENT_DEAD) B.node_kind[node_base + myq[k]] = (uint8_t)TS_NONE;      /* (generation 0 only) nothing to shade, nothing to resolve */
                     else {
@@ -647,19 +620,10 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                 }
             }
             __syncthreads();
-#if !EU_SHADE_FAST_PREP      /* A/B: rounds 1-3 */
+            /* (round 4 measured the exclusive scan of the key counts done by half a wave instead of this loop, and a thread's later queue slots found by a
+             * short walk from its first instead of the ten-step search: 1.41 against 1.27 ms on 3d_room, 8.06 against 8.37 Gray/s with frames in flight --
+             * six more VGPRs in a kernel that sits at 128; removed) */
             if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t k = 0; k < EU_WF_KEYS; k++) { offs[k] = run; run += hist[k]; } n_sorted = run; next_chunk = 0; }
-#else
-            if (threadIdx.x < 64) {      /* exclusive scan of the 32 key counts by half a wave (round 4; one thread's loop of 32 dependent LDS round trips held the whole workgroup for ~1.5 us per window) */
-                const uint32_t lane = threadIdx.x;
-                const uint32_t hk = lane < EU_WF_KEYS ? hist[lane] : 0u;
-                uint32_t inc = hk;
-#pragma unroll
-                for (int off = 1; off < (int)EU_WF_KEYS; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
-                if (lane < EU_WF_KEYS) offs[lane] = inc - hk;
-                if (lane == EU_WF_KEYS - 1) { n_sorted = inc; next_chunk = 0; }
-            }
-#endif
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < EU_WF_WIN / EU_WF_BLOCK; k++) if (mykey[k] != 0xffffffffu) sorted[offs[mykey[k]] + myrank[k]] = myq[k];
@@ -864,10 +828,11 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
 #endif
         }
     }
+    if (threadIdx.x == 0) next_chunk = 0;      /* (every wave is past its last window's chunks: the counter deals the tail's batches next) */
     __syncthreads();
     if constexpr (FUSE >= 0) {
         /* trace_closest of this workgroup's own children (the barrier above made their records visible to all its waves; the same
-         * compute unit wrote them, so its L1 holds nothing stale).  Batches of 64 in queue order; the four waves take them in turn. */
+         * compute unit wrote them, so its L1 holds nothing stale). */
         const uint32_t n_own = seg_fill < B.seg_cap ? seg_fill : B.seg_cap;
         if (n_own != 0u) {
             EuScene S2;
@@ -881,7 +846,12 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                 HS.c = hs_c + wave * hs_cap * 64 + lane;
                 HS.cap = hs_cap;
             }
-            for (uint32_t idx = threadIdx.x; idx - (threadIdx.x & 63u) < n_own; idx += EU_WF_BLOCK) {
+            for (;;) {      /* batches of 64 in queue order, taken by whichever wave is free (a batch of rays inside the glass costs several times a batch that misses everything) */
+                uint32_t batch = 0;
+                if ((threadIdx.x & 63u) == 0) batch = atomicAdd(&next_chunk, 1u);
+                batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
+                if (batch * 64u >= n_own) break;
+                const uint32_t idx = batch * 64u + (threadIdx.x & 63u);
                 if (idx < n_own) {
                     const uint32_t q = out_base + idx;
                     real o[D], d[D];
