@@ -318,13 +318,14 @@ def other_configs(torch, dev, Parser, args, in_flight):
         frame0 = ea.frame(W, H, time=0.0, rows=(0, H))
         rgba0 = torch.zeros((H, W), dtype=torch.int32, device=dev)
         rgb0 = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
-        raw = torch.cuda.current_stream(dev).cuda_stream
+        st0 = torch.cuda.current_stream(dev)
+        raw = st0.cuda_stream
         ts = []
         for k in range(2 + (4 if W * H > (4 << 20) else 9)):
             t1 = time.perf_counter()
             ea.render_device(frame0, rgba0.data_ptr(), None, raw, device=dev.index)
             ea.pack_rgb_device(rgba0.data_ptr(), rgb0.data_ptr(), H * W, raw, device=dev.index)
-            torch.cuda.synchronize(dev)
+            st0.synchronize()
             if k >= 2:
                 ts.append((time.perf_counter() - t1) * 1e3)
         ts.sort()
@@ -567,13 +568,14 @@ def main():
         frame1 = ea.frame(W, H, time=0.0, rows=(0, H))
         rgba1 = torch.zeros((H, W), dtype=torch.int32, device=dev)
         rgb1 = torch.empty((H * W * 3 + 16,), dtype=torch.uint8, device=dev)
-        raw = torch.cuda.current_stream(dev).cuda_stream
+        st1 = torch.cuda.current_stream(dev)
+        raw = st1.cuda_stream
         ts = []
         for k in range(3 + 15):
             t1 = time.perf_counter()
             ea.render_device(frame1, rgba1.data_ptr(), None, raw, device=local_rank)
             ea.pack_rgb_device(rgba1.data_ptr(), rgb1.data_ptr(), H * W, raw, device=local_rank)
-            torch.cuda.synchronize(dev)
+            st1.synchronize()      # hipStreamSynchronize on the stream the frame went to (what eu_render does; hipDeviceSynchronize walks every stream of the device: +15..30 us, tools/alone_sync_forms.py)
             if k >= 3:
                 ts.append((time.perf_counter() - t1) * 1e3)
         ts.sort()
@@ -581,7 +583,7 @@ def main():
         alone = {"ms": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "frames": len(ts), "Mray/s": ea.stats(device=local_rank)["rays"] / ts[len(ts) // 2] / 1e3,
                  "kernel_ms": sum(akms) / max(1, len(akms)),
                  "band_streams": args.streams or "library default",
-                 "note": "launch, pack, wait -- repeat: one renderer with the library's defaults, nothing else in flight (host launch time and the final wait included; kernel_ms = HIP events around the frame's pipeline)"}
+                 "note": "launch, pack, wait (hipStreamSynchronize on the caller's stream) -- repeat: one renderer with the library's defaults, nothing else in flight (host launch time and the final wait included; kernel_ms = HIP events around the frame's pipeline)"}
         alone_rgb = rgb1[:H * W * 3].clone()
         ea.close()
         del rgba1, rgb1
@@ -646,6 +648,12 @@ def main():
                          "algorithmic_bytes": alg_bytes, "valu": valu_figure(workload, kernel_ms), "flops": flops_figure(workload, rays_per_step, kernel_ms),
                          "note": "bound by chains of dependent f64 arithmetic and control flow at 3 waves per SIMD, not by HBM (DESIGN.md section 4); HBM fraction reported because BASELINE asks for it; traffic / valu: profiles/r04_*_pmc.json, profiles/r04_isa_mix.json"},
         }
+        # both methods at the top level, labelled: `value` is throughput with frames in flight; the reference's own call
+        # shape -- one synchronous Environment::render after the other -- is `value_one_frame_at_a_time`
+        out["value_method"] = "%d frames in flight on %d renderers (throughput; inputs resident, barrier + synchronize around the timed region)" % (run["n_slots"], run["n_slots"])
+        if alone is not None:
+            out["value_one_frame_at_a_time"] = alone["Mray/s"]
+            out["value_one_frame_at_a_time_method"] = "one renderer, library defaults, launch + pack + hipStreamSynchronize per frame, default hardware queues apart from GPU_MAX_HW_QUEUES=%s set for the pipelined run" % os.environ.get("GPU_MAX_HW_QUEUES", "4")
         if cfg5 is not None:
             out["config5"] = cfg5
         if cfg5_abi is not None:

@@ -102,6 +102,8 @@ SYMBOLS = {
     "eu_renderer_jit_log": (C.c_char_p, [C.c_void_p]),
     "eu_scene_jit_source": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]),
     "eu_scene_jit_precompile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(JitInfo), C.c_char_p, C.c_size_t]),
+    "eu_scene_jit_source_opts": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint, C.POINTER(C.c_void_p), C.c_char_p]),
+    "eu_scene_jit_precompile_opts": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint, C.POINTER(JitInfo), C.c_char_p, C.c_size_t]),
     "eu_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "eu_pack_rgb_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

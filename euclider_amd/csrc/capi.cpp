@@ -65,9 +65,9 @@ extern "C" const void *eu_scene_flat(const eu_scene *s, size_t *bytes) {
 }
 
 /* ---- scene-specialised kernels (jit.hpp): source and ahead-of-time compilation, no GPU involved ---- */
-extern "C" int eu_scene_jit_source(const eu_scene *scene, char **source, char *key) {
+extern "C" int eu_scene_jit_source_opts(const eu_scene *scene, const char *jit_flags, unsigned renderer_flags, char **source, char *key) {
     if (!scene || !source) return EU_ERR_INVALID_ARGUMENT;
-    const euclider::JitPlan plan = euclider::jit_generate(scene->flat);
+    const euclider::JitPlan plan = euclider::jit_generate(scene->flat, jit_flags ? jit_flags : "", !(renderer_flags & EU_RENDERER_NO_FUSE));
     char *buf = (char *)eu_alloc(plan.source.size() + 1);
     if (!buf) return EU_ERR_INVALID_ARGUMENT;
     memcpy(buf, plan.source.c_str(), plan.source.size() + 1);
@@ -76,9 +76,11 @@ extern "C" int eu_scene_jit_source(const eu_scene *scene, char **source, char *k
     return EU_OK;
 }
 
-extern "C" int eu_scene_jit_precompile(const eu_scene *scene, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen) {
+extern "C" int eu_scene_jit_source(const eu_scene *scene, char **source, char *key) { return eu_scene_jit_source_opts(scene, nullptr, 0u, source, key); }
+
+extern "C" int eu_scene_jit_precompile_opts(const eu_scene *scene, const char *cache_dir, const char *jit_flags, unsigned renderer_flags, eu_jit_info *info, char *err, size_t errlen) {
     if (!scene) return EU_ERR_INVALID_ARGUMENT;
-    const euclider::JitPlan plan = euclider::jit_generate(scene->flat);
+    const euclider::JitPlan plan = euclider::jit_generate(scene->flat, jit_flags ? jit_flags : "", !(renderer_flags & EU_RENDERER_NO_FUSE));
     euclider::JitBuild b;
     const int rc = euclider::jit_build(plan, cache_dir ? cache_dir : "", b);
     if (info) {
@@ -88,5 +90,8 @@ extern "C" int eu_scene_jit_precompile(const eu_scene *scene, const char *cache_
     }
     if (rc != EU_OK) set_err(err, errlen, b.log);
     return rc;
+}
+extern "C" int eu_scene_jit_precompile(const eu_scene *scene, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen) {
+    return eu_scene_jit_precompile_opts(scene, cache_dir, nullptr, 0u, info, err, errlen);
 }
 

@@ -7,6 +7,7 @@
 
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -25,7 +26,7 @@
 
 namespace euclider {
 
-#define EU_JIT_VERSION "eu-jit-4"
+#define EU_JIT_VERSION "eu-jit-5"
 
 /* the device headers, embedded at build time (csrc/Makefile: jit_headers.inc) */
 struct EmbeddedHeader { const char *name; const char *text; };
@@ -93,6 +94,14 @@ struct Gen {
     std::set<std::pair<uint32_t, uint32_t>> inside_done;
     std::string inside_defs;      /* static member functions in_<first>_<root>(p) */
 
+    /* Straight-line code is worth its compile time up to a point (jit.hpp: kJitOpsBudget, kJitSurfacesBudget).  Entities are taken in
+     * order while their shape programs fit the budget; the others are traced by the interpreter's routines from the flat scene
+     * (trace_device.h: interp_entities, inside_subtree, hit_normal) -- at their place in the entity order.  Surfaces beyond theirs are
+     * evaluated from their records (surface_color; its operand stack lies in dynamic LDS: JitPlan::color_stack). */
+    uint32_t ops_budget = kJitOpsBudget, surfaces_budget = kJitSurfacesBudget;
+    std::vector<uint8_t> straight;      /* per entity */
+    uint32_t n_straight_ops = 0, n_interp_entities = 0, n_generic_surfaces = 0;
+
     explicit Gen(const FlatScene &flat) : w(flat.words.data()), h(&flat.header()), D((int)flat.header().dim) {}
 
     OpView op(uint32_t i) const {
@@ -149,19 +158,63 @@ struct Gen {
      * visible the optimiser shares plane hits between 4d_frame's concentric boxes and keeps them all alive -- 912 SGPR spills,
      * 2.6 against 3.9 Gray/s. */
     bool shape_params_in_memory = true;
+    /* (`po`, `bo`: offsets in reals of the entity at hand behind the entity the code was written for -- zero, a constant, except in
+     * the loop over a run of congruent entities: find_runs) */
     std::string op_params(const std::string &name, uint32_t i) const {
         const OpView p = op(i);
         if (!shape_params_in_memory) return real_array(name, params(p.param), param_count(p));
         char b[160];
-        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + %uu;", name.c_str(), h->off_params, p.param);
+        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + (%uu + po);", name.c_str(), h->off_params, p.param);
         return b;
     }
     std::string bound_array(const std::string &name, uint32_t bi) const {
         if (!shape_params_in_memory) return real_array(name, bounds(bi), (uint32_t)D + 2);
         char b[160];
-        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + %uu;", name.c_str(), h->off_bounds, (uint32_t)(D + 2) * bi);
+        snprintf(b, sizeof b, "const real *const %s = (const real *)(S.w + %uu) + (%uu + bo);", name.c_str(), h->off_bounds, (uint32_t)(D + 2) * bi);
         return b;
     }
+
+    /* Runs of CONGRUENT entities: consecutive surfaced entities whose shape programs are the same operations on parameters and bounding
+     * spheres that lie a constant stride apart in the flat scene (a row of identical columns, 4d_cylinders' eight crosses).  Such a run
+     * gets ONE body in a loop over its entities -- in entity order, as trace_closest wants -- with the stride added to every address
+     * (wave-uniform: still scalar loads): an eighth of the code to compile and to fetch. */
+    struct Run { uint32_t e0, count, n_ops, dp, db; };      /* dp: reals between two entities' parameters; db: bounding spheres between theirs */
+    std::vector<Run> runs;
+    std::vector<int> run_of;           /* per entity: index into runs, or -1 */
+    bool congruent(uint32_t ea, uint32_t eb, uint32_t &dp, uint32_t &db, bool &have_dp, bool &have_db) const {
+        const EntityView A = entity(ea), B = entity(eb);
+        if (A.surface < 0 || B.surface < 0) return false;
+        const uint32_t n = A.shape_root - A.shape_first + 1u;
+        if (B.shape_root - B.shape_first + 1u != n || B.shape_first != A.shape_first + n) return false;
+        if ((A.bound == 0xffffffffu) != (B.bound == 0xffffffffu)) return false;
+        auto same = [](uint32_t d, uint32_t &acc, bool &have) { if (!have) { acc = d; have = true; return true; } return acc == d; };
+        if (A.bound != 0xffffffffu && (B.bound <= A.bound || !same(B.bound - A.bound, db, have_db))) return false;
+        for (uint32_t k = 0; k < n; k++) {
+            const OpView p = op(A.shape_first + k), q = op(B.shape_first + k);
+            if (p.kind != q.kind || p.count != q.count || p.first - A.shape_first != q.first - B.shape_first) return false;
+            if (p.kind == EU_SH_SKIP) { if (q.param <= p.param || !same(q.param - p.param, db, have_db)) return false; }
+            else if (p.kind < EU_SH_UNION || p.kind >= EU_SH_CHAIN_UNION) { if (p.kind != EU_SH_VOID && (q.param <= p.param || !same(q.param - p.param, dp, have_dp))) return false; }
+        }
+        return true;
+    }
+    void find_runs() {
+        const uint32_t ne = h->n_entities;
+        run_of.assign(ne, -1);
+        if (!shape_params_in_memory || no_runs) return;
+        for (uint32_t e = 0; e + 1 < ne;) {
+            uint32_t dp = 0, db = 0; bool have_dp = false, have_db = false;
+            uint32_t last = e;
+            while (last + 1 < ne && congruent(last, last + 1, dp, db, have_dp, have_db)) last++;
+            const EntityView E = entity(e);
+            const uint32_t n = E.shape_root - E.shape_first + 1u;
+            if (last > e && n >= 4u) {      /* (a run of bare leaves is not worth a loop) */
+                for (uint32_t k = e; k <= last; k++) run_of[k] = (int)runs.size();
+                runs.push_back(Run{e, last - e + 1u, n, have_dp ? dp : 0u, have_db ? db : 0u});
+                e = last + 1;
+            } else e++;
+        }
+    }
+    bool no_runs = false;              /* tuning / tests: -DEU_JIT_NO_RUNS */
 
     /* ---- is_point_inside of the subtree ops[first..root] (shape.rs:589-600) as an expression; see inside_subtree() ---- */
     std::string inside_fn(uint32_t first, uint32_t root) {
@@ -169,7 +222,7 @@ struct Gen {
         snprintf(nm, sizeof nm, "in_%u_%u", first, root);
         if (inside_done.insert({first, root}).second) {
             Out d;
-            d.f("    static EU_DEV bool %s(const EuScene &S, const real *p) {\n", nm);
+            d.f("    static EU_DEV bool %s(const EuScene &S, const real *p, uint32_t po = 0u, uint32_t bo = 0u) {\n", nm);
             std::vector<std::string> st;
             emit_inside_range(d, first, root, root, st);
             d.f("        return %s;\n    }\n", st.empty() ? "false" : st.back().c_str());
@@ -235,11 +288,11 @@ struct Gen {
                 continue;
             }
             if (p.kind >= EU_SH_CHAIN_UNION) {
-                d.f("%sCsgList %s; { %s %s = push_chain<%d>(%s, %uu, P, o, d, hs, sp, %uu, cnt, use_box, fail); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D,
+                d.f("%sCsgList %s; { %s %s = push_chain<%d>(%s, %uu, P, o, d, hs, sp, %uu + oo, cnt, use_box, fail); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D,
                     kind_name(p.kind), p.count, i);
                 st.push_back(v);
             } else if (p.kind < EU_SH_UNION) {
-                d.f("%sCsgList %s; { %s %s = push_leaf<%d>(%s, P, o, d, hs, sp, %uu, cnt); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D, kind_name(p.kind), i);
+                d.f("%sCsgList %s; { %s %s = push_leaf<%d>(%s, P, o, d, hs, sp, %uu + oo, cnt); }\n", ind.c_str(), v, op_params("P", i).c_str(), v, D, kind_name(p.kind), i);
                 st.push_back(v);
             } else {
                 if (st.size() < 2) { d.f("%s/* malformed program at op %u */\n", ind.c_str(), i); continue; }
@@ -248,7 +301,7 @@ struct Gen {
                 const std::string b = st.back(); st.pop_back();
                 const std::string a = st.back(); st.pop_back();
                 const std::string ia = inside_fn(fa, ra), ib = inside_fn(fb, rb);
-                d.f("%sconst CsgList %s = csg_merge<%d>(%s, %s, hs, sp, %s, %s, o, d, cnt, [&S](const real *q) { return %s(S, q); }, [&S](const real *q) { return %s(S, q); });\n",
+                d.f("%sconst CsgList %s = csg_merge<%d>(%s, %s, hs, sp, %s, %s, o, d, cnt, [&](const real *q) { return %s(S, q, po, bo); }, [&](const real *q) { return %s(S, q, po, bo); });\n",
                     ind.c_str(), v, D, kind_name(p.kind), i == root ? "true" : "false", a.c_str(), b.c_str(), ia.c_str(), ib.c_str());
                 st.push_back(v);
             }
@@ -358,7 +411,8 @@ struct Gen {
 
     void generate() {
         const uint32_t ne = h->n_entities;
-        o.f("/* generated by euclider_amd (%s): trace kernels specialised for one scene: %u entities, %u shape ops, dim %d */\n", EU_JIT_VERSION, ne, h->n_ops, D);
+        o.f("/* generated by euclider_amd (%s): trace kernels specialised for one scene: %u entities, %u shape ops, dim %d (budgets: %u ops, %u surfaces) */\n", EU_JIT_VERSION, ne, h->n_ops, D,
+            ops_budget, surfaces_budget);
         /* tuning of the specialised shade kernel (measured with `--jit-flags`, one call per sweep): windows of 2048 rays sorted together
          * where there are surfaces to sort by (three or more; the kernel halves and quarters its windows by itself when a launch is
          * small; 4d_frame, one surface, loses 1 % with the larger window) and launch bounds of two waves per SIMD -- the
@@ -374,16 +428,40 @@ struct Gen {
         tc.f("    /* trace_closest (universe/mod.rs:85-147): every surfaced entity's shape program as a straight line */\n");
         tc.f("    template <class HS>\n    static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, int use_box, bool &fail,\n"
              "                                     bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {\n");
+        straight.assign(ne, 0);
+        find_runs();
+        for (uint32_t e = 0; e < ne; e++) {
+            const EntityView E = entity(e);
+            const uint32_t n = E.shape_root - E.shape_first + 1u;
+            const uint32_t members = run_of[e] >= 0 ? runs[(size_t)run_of[e]].count : 1u;      /* (a run's body is written once) */
+            if (n_straight_ops + n <= ops_budget) { for (uint32_t k = 0; k < members; k++) straight[e + k] = 1; n_straight_ops += n; }
+            else n_interp_entities += members;
+            e += members - 1u;
+        }
         for (uint32_t e = 0; e < ne; e++) {
             const EntityView E = entity(e);
             if (E.surface < 0) continue;
-            tc.f("        {   /* entity %u: ops %u..%u */\n", e, E.shape_first, E.shape_root);
+            const Run *run = (straight[e] && run_of[e] >= 0) ? &runs[(size_t)run_of[e]] : nullptr;
+            if (!straight[e]) {      /* this entity and what follows it, up to the next one with code of its own */
+                uint32_t e2 = e + 1;
+                while (e2 < ne && (entity(e2).surface < 0 || !straight[e2])) e2++;
+                tc.f("        interp_entities<%d>(S, %uu, %uu, o, d, hs, cnt, use_box, fail, have, best_t, best_code, best_ent);\n", D, e, e2);
+                e = e2 - 1;
+                continue;
+            }
+            if (run) {
+                tc.f("        _Pragma(\"nounroll\") for (uint32_t ge = 0; ge < %uu; ge++) {   /* entities %u..%u: congruent, ops %u..%u each */\n"
+                     "            const uint32_t po = ge * %uu, bo = ge * %uu, oo = ge * %uu;\n", run->count, e, e + run->count - 1u, E.shape_first, E.shape_root,
+                     run->dp, run->db * (uint32_t)(D + 2), run->n_ops);
+            } else {
+                tc.f("        {   /* entity %u: ops %u..%u */\n            constexpr uint32_t po = 0u, bo = 0u, oo = 0u;\n", e, E.shape_first, E.shape_root);
+            }
             std::string ind = "            ";
             if (E.bound != 0xffffffffu) { tc.f("            %s\n            if (!ray_misses_bound<%d>(B, o, d)) {\n", bound_array("B", E.bound).c_str(), D); ind += "    "; }
             tc.f("%sreal t = R(0.0); uint32_t code = 0, n;\n", ind.c_str());
             if (E.shape_first == E.shape_root) {
                 const OpView p = op(E.shape_root);
-                tc.f("%s{ %s n = eval_single<%d>(%s, %uu, P, o, d, hs, %uu, cnt, t, code, use_box, fail); }\n", ind.c_str(), op_params("P", E.shape_root).c_str(), D,
+                tc.f("%s{ %s n = eval_single<%d>(%s, %uu, P, o, d, hs, %uu + oo, cnt, t, code, use_box, fail); }\n", ind.c_str(), op_params("P", E.shape_root).c_str(), D,
                      kind_name(p.kind), p.count, E.shape_root);
             } else {
                 tc.f("%s{ uint32_t sp = 0;\n", ind.c_str());
@@ -391,22 +469,43 @@ struct Gen {
                 emit_tree_range(tc, E.shape_first, E.shape_root, E.shape_root, st, ind + "  ");
                 tc.f("%s  n = csg_root_result(%s, hs, cnt, t, code); }\n", ind.c_str(), st.empty() ? "CsgList{0u, false, false}" : st.back().c_str());
             }
-            tc.f("%sif (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = %uu; }\n", ind.c_str(), e);
+            tc.f("%sif (n != 0 && (!have || best_t > t)) { have = true; best_t = t; best_code = code; best_ent = %uu%s; }\n", ind.c_str(), e, run ? " + ge" : "");
             if (E.bound != 0xffffffffu) tc.f("            }\n");
             tc.f("        }\n");
+            if (run) e += run->count - 1u;
         }
         tc.f("    }\n");
 
         /* ---- hit_normal ---- */
         Out hn;
-        hn.f("    static EU_DEV void hit_normal(const EuScene &S, uint32_t ent, uint32_t code, const real *o, const real *d, const real *loc, real *n) {\n"
-             "        switch (code & 0xffffu) {\n");
+        hn.f("    static EU_DEV void hit_normal(const EuScene &S, uint32_t ent, uint32_t code, const real *o, const real *d, const real *loc, real *n) {\n");
+        {
+            bool any_run = false;
+            for (const Run &r : runs) any_run = any_run || straight[r.e0];
+            if (!any_run) hn.f("        const uint32_t opi = code & 0xffffu;\n        constexpr uint32_t po = 0u;\n");
+            else {      /* a leaf of a run's entity k: the case of the run's first entity, its parameters k strides further on */
+                hn.f("        uint32_t opi = code & 0xffffu, po = 0u;\n");
+                for (const Run &r : runs) {
+                    if (!straight[r.e0]) continue;
+                    const uint32_t f0 = entity(r.e0).shape_first;
+                    hn.f("        if (opi - %uu < %uu) { const uint32_t ge = (opi - %uu) / %uu; opi -= ge * %uu; po = ge * %uu; }\n", f0, r.count * r.n_ops, f0, r.n_ops, r.n_ops, r.dp);
+                }
+            }
+        }
+        hn.f("        switch (opi) {\n");
         for (uint32_t e = 0; e < ne; e++) {
             const EntityView E = entity(e);
-            if (E.surface < 0) continue;
+            if (E.surface < 0 || !straight[e]) continue;
+            const bool in_run = run_of[e] >= 0;
+            if (in_run && runs[(size_t)run_of[e]].e0 != e) continue;      /* (written once, for the run's first entity) */
             for (uint32_t i = E.shape_first; i <= E.shape_root; i++) {
                 const OpView p = op(i);
                 if (p.kind == EU_SH_SKIP || (p.kind >= EU_SH_UNION && p.kind < EU_SH_CHAIN_UNION) || p.kind == EU_SH_VOID) continue;
+                if (p.kind >= EU_SH_CHAIN_UNION && in_run) {      /* (no table of constants: the normals differ from entity to entity) */
+                    hn.f("        case %uu: { %s const real *const Q = P + ((code >> 16) & 0xffu) * %uu;\n", i, op_params("P", i).c_str(), 2u * (uint32_t)D + 2u);
+                    for (int m = 0; m < D; m++) hn.f("            n[%d] = Q[%d];\n", m, D + 2 + m);
+                    hn.f("            break; }\n");
+                } else
                 if (p.kind >= EU_SH_CHAIN_UNION) {      /* a chain's leaf counts as a half-space: its normal is the stored n * -signum (shape.rs:860) */
                     const real *P = params(p.param);
                     hn.f("        case %uu: { static constexpr real NF[%u][%d] = {", i, p.count, D);
@@ -423,7 +522,9 @@ struct Gen {
                 }
             }
         }
-        hn.f("        default: break;\n        }\n        if (code & EU_HIT_FLIP) {\n");
+        if (n_interp_entities) hn.f("        default: ::hit_normal<%d>(S, code, o, d, loc, n); return;      /* a leaf of an entity without code of its own */\n", D);
+        else hn.f("        default: break;\n");
+        hn.f("        }\n        if (code & EU_HIT_FLIP) {\n");
         for (int m = 0; m < D; m++) hn.f("            n[%d] = -n[%d];\n", m, m);
         hn.f("        }\n    }\n");
 
@@ -431,7 +532,14 @@ struct Gen {
         Out sf;
         std::map<int32_t, std::vector<uint32_t>> by_surface;
         for (uint32_t e = 0; e < ne; e++) { const EntityView E = entity(e); if (E.surface >= 0) by_surface[E.surface].push_back(e); }
+        std::set<int32_t> own_surface;      /* surfaces with a function of their own: in the order their first entity comes */
+        for (uint32_t e = 0; e < ne; e++) {
+            const EntityView E = entity(e);
+            if (E.surface >= 0 && !own_surface.count(E.surface) && own_surface.size() < surfaces_budget) own_surface.insert(E.surface);
+        }
+        n_generic_surfaces = (uint32_t)(by_surface.size() - own_surface.size());
         for (auto &kv : by_surface) {
+            if (!own_surface.count(kv.first)) continue;
             const EuFlatSurface *F = surface((uint32_t)kv.first);
             sf.f("    static EU_DEV void surf_%d(const EuScene &S, HitCtx<%d> &c, real time_s, LaneCounters &cnt, SurfaceEval<%d> &E) {\n", kv.first, D, D);
             sf.f("        static constexpr EuFlatSurface F = {%uu, %uu, %uu, %uu, %s, %s, %s, %s, {0.0, 0.0}};\n", F->ratio_kind, F->thr_kind, F->color_first, F->color_root,
@@ -467,16 +575,37 @@ struct Gen {
         sf.f("    static EU_DEV void surface(const EuScene &S, uint32_t ent, HitCtx<%d> &c, real time_s, LaneCounters &cnt, real *cst, uint32_t stride, SurfaceEval<%d> &E) {\n"
              "        switch (ent) {\n", D, D);
         for (auto &kv : by_surface) {
+            if (!own_surface.count(kv.first)) continue;
             sf.f("       ");
             for (uint32_t e : kv.second) sf.f(" case %uu:", e);
             sf.f(" surf_%d(S, c, time_s, cnt, E); break;\n", kv.first);
         }
-        sf.f("        default: E.ratio = R(0.0); E.have_color = false; E.translucent = false; E.spx = 0; E.sc = Rgba{R(0.0), R(0.0), R(0.0), R(0.0)}; break;\n        }\n    }\n");
+        if (n_generic_surfaces)
+            sf.f("        default: {      /* a surface without a function of its own: from its records, as the interpreter kernels do */\n"
+                 "            const EuFlatSurface *F = S.surface((uint32_t)S.entity(ent).surface);\n"
+                 "            surface_eval<%d>(F, c, cnt, E, [&]() { return surface_color<%d>(S, F, c, time_s, cnt, cst, stride); });\n            break; }\n", D, D);
+        else
+        sf.f("        default: E.ratio = R(0.0); E.have_color = false; E.translucent = false; E.spx = 0; E.sc = Rgba{R(0.0), R(0.0), R(0.0), R(0.0)}; break;\n");
+        sf.f("        }\n    }\n");
 
         /* ---- material_at (universe/mod.rs:229-251): first entity containing the point ---- */
         Out ma;
         ma.f("    static EU_DEV int material_at(const EuScene &S, const real *p) {\n");
-        for (uint32_t e = 0; e < ne; e++) { const EntityView E = entity(e); ma.f("        if (%s(S, p)) return %u;\n", inside_fn(E.shape_first, E.shape_root).c_str(), e); }
+        for (uint32_t e = 0; e < ne; e++) {
+            const EntityView E = entity(e);
+            if (straight[e] && run_of[e] >= 0) {
+                const Run &r = runs[(size_t)run_of[e]];
+                ma.f("        _Pragma(\"nounroll\") for (uint32_t ge = 0; ge < %uu; ge++) if (%s(S, p, ge * %uu, ge * %uu)) return (int)(%uu + ge);\n", r.count,
+                     inside_fn(E.shape_first, E.shape_root).c_str(), r.dp, r.db * (uint32_t)(D + 2), e);
+                e += r.count - 1u;
+                continue;
+            }
+            if (straight[e]) { ma.f("        if (%s(S, p)) return %u;\n", inside_fn(E.shape_first, E.shape_root).c_str(), e); continue; }
+            uint32_t e2 = e + 1;
+            while (e2 < ne && !straight[e2]) e2++;
+            ma.f("        { const int r = material_at_range<%d>(S, %uu, %uu, p); if (r >= 0) return r; }\n", D, e, e2);
+            e = e2 - 1;
+        }
         ma.f("        return -1;\n    }\n");
 
         /* ---- Material::enter / exit of the material of entity `ent` ---- */
@@ -544,9 +673,16 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags, bool
     for (auto &f : plan.extra_flags)      /* tuning experiments (bench.py --jit-flags=-DEU_HS_CAP=16): a smaller stack than the static bound; a lane that needs more marks the frame (EU_CNT_HS_FULL) */
         if (f == "-DEU_HS_PRIVATE") plan.hs_lds = false;
         else if (f.rfind("-DEU_HS_CAP=", 0) == 0) { const unsigned v = (unsigned)atoi(f.c_str() + 12); if (v >= 4 && v <= 96) { plan.hs_cap = v; plan.hs_lds = v <= 24; } }
-    plan.too_large = h.n_ops > kJitMaxShapeOps || h.n_entities > kJitMaxEntities;
     Gen g(flat);
+    for (auto &f : plan.extra_flags)      /* (tests and tuning: small budgets put every scene on the mixed path) */
+        if (f.rfind("-DEU_JIT_OPS_BUDGET=", 0) == 0) g.ops_budget = (uint32_t)strtoul(f.c_str() + 20, nullptr, 10);
+        else if (f.rfind("-DEU_JIT_SURFACES_BUDGET=", 0) == 0) g.surfaces_budget = (uint32_t)strtoul(f.c_str() + 25, nullptr, 10);
+        else if (f == "-DEU_JIT_NO_RUNS") g.no_runs = true;
     g.generate();
+    plan.n_straight_ops = g.n_straight_ops;
+    plan.n_interp_entities = g.n_interp_entities;
+    plan.n_generic_surfaces = g.n_generic_surfaces;
+    plan.color_stack = g.n_generic_surfaces != 0;
     Out tail;
     const unsigned hscap = plan.hs_lds ? 0u : plan.hs_cap;
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_ISECT_WAVES) void eu_jit_intersect0(const uint64_t *__restrict__ scene_g, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,\n"
@@ -640,11 +776,6 @@ static std::string library_cache_dir() {      /* <directory of this shared libra
 }
 
 int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out, bool cache_only) {
-    if (plan.too_large) {
-        out.log = "the scene is too large to specialise (more than " + std::to_string(kJitMaxShapeOps) + " shape operations or " + std::to_string(kJitMaxEntities) +
-                  " entities): the interpreter kernels trace it";
-        return EU_ERR_CAPACITY;
-    }
 #if EU_REAL_BITS == 32
     const std::string fname = plan.key + "_f32.hsaco";
 #else

@@ -31,13 +31,17 @@ struct JitPlan {
     std::string key;             /* hex digest of everything the code object depends on */
     bool fused = true;           /* the module holds the fused kernels (intersect0, fshade0, fshade: one launch per generation) or the two-kernel pipeline's
                                   * (intersect0, intersect, shade0, shade: eu_renderer_opts.flags & EU_RENDERER_NO_FUSE) */
-    bool too_large = false;      /* the scene has more shape ops / entities than straight-line code is worth compiling for (jit_build refuses) */
+    /* what did not fit the budgets below and is traced / shaded from the flat scene inside the specialised kernels */
+    uint32_t n_straight_ops = 0, n_interp_entities = 0, n_generic_surfaces = 0;
+    bool color_stack = false;    /* the shade kernels need surface_color's operand stack in dynamic LDS (color_depth RGBA entries per lane) */
 };
 
 /* Straight-line code for every entity compiles in time that grows faster than the scene (3d_room: 10 shape ops, 6 s; 4d_cylinders: 248
- * ops, 38 s; a random scene of 266 ops: 166 s; 600 ops: more than ten minutes): beyond these limits a renderer keeps the interpreter
- * kernels (eu_jit_info.active = 0). */
-constexpr uint32_t kJitMaxShapeOps = 256, kJitMaxEntities = 48;
+ * ops, 73 s for the fused kernels; a random scene of 266 ops: 166 s; 600 ops: more than ten minutes).  So the generator has budgets:
+ * entities get straight-line code, in entity order, while the shape operations of those that have it stay within kJitOpsBudget, and
+ * the first kJitSurfacesBudget distinct surfaces get a function of their own.  The rest of a larger scene is traced and shaded by
+ * the interpreter's routines INSIDE the specialised kernels (rounds 2-3 gave such a scene the interpreter kernels altogether). */
+constexpr uint32_t kJitOpsBudget = 256, kJitSurfacesBudget = 48;
 
 /* Pure host code (no HIP call): the specialised translation unit for this scene. */
 JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags = std::string(), bool fused = true);

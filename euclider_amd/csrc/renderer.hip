@@ -111,6 +111,7 @@ struct eu_renderer {
     hipFunction_t jit_fshade = nullptr, jit_fshade0 = nullptr;      /* the fused forms: shade, then intersect the rays just queued */
     bool fuse = true;                        /* a generation is ONE launch (fused shade + intersect) where such kernels exist (eu_renderer_opts.flags: EU_RENDERER_NO_FUSE) */
     bool jit_hs_lds = true;
+    bool jit_color_stack = false;      /* the specialised shade kernels evaluate some surfaces from their records: colour-operand stack in dynamic LDS */
     uint32_t jit_hs_cap = 0;
     eu_jit_info jit = {};
     std::string jit_log;
@@ -194,7 +195,10 @@ static void renderer_load_jit(eu_renderer *r, const euclider::JitPlan &plan, con
     /* producer workgroups per CU = what the producer kernels' registers and LDS allow.  (A renderer that switches kernels between two
      * frames -- EU_SPECIALIZE_ASYNC -- keeps its buffers: wf_launch_frame uses at most the segments they were cut into.) */
     const bool fused = r->jit_fshade != nullptr;
-    const size_t dyn = fused && plan.hs_lds ? (size_t)(EU_WF_BLOCK / 64) * plan.hs_cap * 64 * (sizeof(real) + 4) : 0;
+    r->jit_color_stack = plan.color_stack;
+    const size_t color_lds = plan.color_stack ? (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(real) * EU_WF_BLOCK : 0;      /* (surfaces beyond the generator's budget: jit.hpp) */
+    const size_t hs_lds_bytes = fused && plan.hs_lds ? (size_t)(EU_WF_BLOCK / 64) * plan.hs_cap * 64 * (sizeof(real) + 4) : 0;
+    const size_t dyn = hs_lds_bytes > color_lds ? hs_lds_bytes : color_lds;
     if (dyn > 64 * 1024) {      /* beyond the default limit of dynamic LDS per workgroup */
         (void)hipFuncSetAttribute((const void *)r->jit_fshade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         (void)hipFuncSetAttribute((const void *)r->jit_fshade0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
@@ -569,7 +573,7 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
      * workgroups per CU still fit (160 KB / 3, minus ~8 KB static), a copy of the flat scene; the specialised one needs neither */
     const size_t color_lds = (size_t)(r->color_depth ? r->color_depth : 1u) * 4 * sizeof(real) * EU_WF_BLOCK;
     const bool shade_lds = (size_t)r->scene_words * 8 + color_lds <= 44 * 1024 && !(r->opts.flags & EU_RENDERER_SHADE_SCENE_GLOBAL);
-    const size_t shade_dyn = jit ? 0 : (shade_lds ? (size_t)r->scene_words * 8 + color_lds : color_lds);
+    const size_t shade_dyn = jit ? (r->jit_color_stack ? color_lds : 0) : (shade_lds ? (size_t)r->scene_words * 8 + color_lds : color_lds);
     /* one launch per generation where a fused kernel exists: the specialised module's, or -- interpreter -- the ones with the hit stack
      * and the scene copy in LDS (deeper stacks and larger scenes keep the two-kernel pipeline) */
     const bool fuse = jit ? r->jit_fshade != nullptr : (r->fuse && hs_lds && shade_lds);
@@ -653,13 +657,13 @@ static int wf_launch_frame(eu_renderer *r, hipStream_t caller_stream, const EuDe
                         HIP_TRY(hipModuleLaunchKernel(r->jit_fshade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)fshade_dyn, stream, sa, nullptr));
                     } else if (g == 0) {
                         void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&cam, (void *)&df, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&hit_t, (void *)&point};
-                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade0, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)shade_dyn, stream, sa, nullptr));
                     } else if (tail) {
                         void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&hs_cap, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
                         HIP_TRY(hipModuleLaunchKernel(r->jit_fshade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)fshade_dyn, stream, sa, nullptr));
                     } else {
                         void *sa[] = {(void *)&scene, (void *)&r->scene_words, (void *)&gen, (void *)&max_depth, (void *)&time_s, (void *)&B, (void *)&counters, (void *)&rgba, (void *)&point};
-                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, 0, stream, sa, nullptr));
+                        HIP_TRY(hipModuleLaunchKernel(r->jit_shade, g_prod, 1, 1, EU_WF_BLOCK, 1, 1, (unsigned)shade_dyn, stream, sa, nullptr));
                     }
                 } else {
                     if (isect_now && g == 0) {

@@ -1068,13 +1068,14 @@ EU_DEV void hit_normal(const EuScene &S, uint32_t code, const real *o, const rea
 }
 
 /* Universe::material_at (universe/mod.rs:229-251): first entity containing the point */
-template <int D> EU_DEV int material_at(const EuScene &S, const real *p) {
-    for (uint32_t e = 0; e < S.n_entities; e++) {
+template <int D> EU_DEV int material_at_range(const EuScene &S, uint32_t e0, uint32_t e1, const real *p) {
+    for (uint32_t e = e0; e < e1; e++) {
         const EuScene::EntityView E = S.entity(e);
         if (inside_subtree<D>(S, E.shape_first, E.shape_root, p)) return (int)e;
     }
     return -1;
 }
+template <int D> EU_DEV int material_at(const EuScene &S, const real *p) { return material_at_range<D>(S, 0u, S.n_entities, p); }
 
 /* ------------------------------------------------------------------ materials */
 /* LinearSpace expressions: meval evaluates in f64 whatever F is and the result is cast to F (material.rs:99-111), so these
@@ -1622,21 +1623,30 @@ EU_DEV void surface_eval(const EuFlatSurface *F, HitCtx<D> &c, LaneCounters &cnt
  * answered by walking the flat scene (shape programs, colour programs, RPN code).  A scene-specialised policy (generated and
  * compiled when the renderer is created, jit.cpp) answers the same questions with straight-line code for ONE scene; both call the
  * arithmetic of this header, so they cannot differ in a single bit. */
+/* trace_closest's loop (universe/mod.rs:85-147) over the entities [e0, e1), their shape programs read from the flat scene: the whole
+ * scene for the interpreter kernels; for the specialised kernels the entities whose programs did not fit the generator's budget of
+ * straight-line code (jit.cpp) -- in entity order between the others, so that the strict minimum sees them in the reference's order. */
+template <int D, class HS>
+EU_DEV void interp_entities(const EuScene &S, uint32_t e0, uint32_t e1, const real *o, const real *d, HS &hs, LaneCounters &cnt, int use_box, bool &fail,
+                            bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {
+    for (uint32_t e = e0; e < e1; e++) {
+        const EuScene::EntityView E = S.entity(e);
+        if (E.surface < 0) continue;
+        if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
+        real t = R(0.0); uint32_t code = 0;
+        const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, hs, cnt, t, code, use_box, fail);
+        if (n == 0) continue;
+        if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
+    }
+}
+
 template <int D> struct EuInterp {
     static constexpr bool kInterpreter = true;
     /* trace_closest (universe/mod.rs:85-147): first hit of every surfaced entity, strict minimum */
     template <class HS>
     static EU_DEV void trace_closest(const EuScene &S, const real *o, const real *d, HS &hs, LaneCounters &cnt, int use_box, bool &fail,
                                      bool &have, real &best_t, uint32_t &best_code, uint32_t &best_ent) {
-        for (uint32_t e = 0; e < S.n_entities; e++) {
-            const EuScene::EntityView E = S.entity(e);
-            if (E.surface < 0) continue;
-            if (E.bound != 0xffffffffu && ray_misses_bound<D>(S.bounds(E.bound, D), o, d)) continue;
-            real t = R(0.0); uint32_t code = 0;
-            const uint32_t n = eval_shape<D>(S, E.shape_first, E.shape_root, o, d, hs, cnt, t, code, use_box, fail);
-            if (n == 0) continue;
-            if (!have || best_t > t) { have = true; best_t = t; best_code = code; best_ent = e; }
-        }
+        interp_entities<D>(S, 0u, S.n_entities, o, d, hs, cnt, use_box, fail, have, best_t, best_code, best_ent);
     }
     static EU_DEV void hit_normal(const EuScene &S, uint32_t ent, uint32_t code, const real *o, const real *d, const real *loc, real *n) {
         ::hit_normal<D>(S, code, o, d, loc, n);

@@ -614,6 +614,8 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                     const uint32_t he = B.hit[in][myq[k]].ent;
                     if (he == EU_WF_ENT_DEAD) B.node_kind[node_base + myq[k]] = (uint8_t)TS_NONE;      /* (generation 0 only) nothing to shade, nothing to resolve */
                     else {
+                        /* (round 4 measured the keys in the order "most expensive surface first", so that what a wave waits for at the window's
+                         * last barrier is a chunk of wall rays, not of glass rays: 1.31-1.35 against 1.30 ms on 3d_room, the others within noise) */
                         mykey[k] = he < EU_WF_KEYS - 1 ? he : EU_WF_KEYS - 1;
                         myrank[k] = atomicAdd(&hist[mykey[k]], 1u);
                     }
@@ -830,6 +832,7 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
     }
     if (threadIdx.x == 0) next_chunk = 0;      /* (every wave is past its last window's chunks: the counter deals the tail's batches next) */
     __syncthreads();
+    WF_SUB(13);
     if constexpr (FUSE >= 0) {
         /* trace_closest of this workgroup's own children (the barrier above made their records visible to all its waves; the same
          * compute unit wrote them, so its L1 holds nothing stale). */
@@ -860,15 +863,24 @@ EU_DEV void wf_shade_body(const uint64_t *__restrict__ scene_g, uint32_t scene_w
                     real best_t = R(0.0);
                     uint32_t best_code = 0, best_ent = EU_WF_ENT_MISS;
                     cnt.rays++;
+#ifdef EU_PROFILE_SHADE_WAVE      /* (the shape routines' own stamps belong to the EU_PROFILE_SHAPE build) */
+                    unsigned long long *const prof_rows_keep = cnt.prof;
+                    cnt.prof = nullptr;
+#endif
                     P::trace_closest(S2, o, d, HS, cnt, 2, fail, have, best_t, best_code, best_ent);
+#ifdef EU_PROFILE_SHADE_WAVE
+                    cnt.prof = prof_rows_keep;
+#endif
                     EuWfHit h;
                     h.t = best_t; h.code = best_code; h.ent = best_ent;
 #if EU_REAL_BITS == 32
                     h.pad = 0;
 #endif
                     B.hit[outb][q] = h;
+                    WF_SUB(12);
                 }
             }
+            WF_SUB(14);
         }
     }
     if (threadIdx.x == 0) {

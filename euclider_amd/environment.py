@@ -151,10 +151,10 @@ class Environment:
                 "hit_stack_entries": info.hit_stack_entries, "compile_ms": info.compile_ms, "key": info.key.decode(),
                 "log": (self._L.eu_renderer_jit_log(self.renderer(device)) or b"").decode(errors="replace")}
 
-    def jit_source(self):
-        """The HIP source of this scene's specialised kernels (no GPU needed)."""
+    def jit_source(self, jit_flags=None, renderer_flags=0):
+        """The HIP source of this scene's specialised kernels (no GPU needed); jit_flags / renderer_flags as in eu_renderer_opts."""
         src, key = C.c_void_p(), C.create_string_buffer(40)
-        rc = self._L.eu_scene_jit_source(self._scene, C.byref(src), key)
+        rc = self._L.eu_scene_jit_source_opts(self._scene, jit_flags.encode() if jit_flags else None, renderer_flags, C.byref(src), key)
         if rc != _capi.EU_OK:
             raise EuError(rc)
         try:
@@ -162,10 +162,11 @@ class Environment:
         finally:
             self._L.eu_free(src)
 
-    def jit_precompile(self, cache_dir=None):
+    def jit_precompile(self, cache_dir=None, jit_flags=None, renderer_flags=0):
         """Compile this scene's specialised kernels for gfx950 into the cache (no GPU needed); returns eu_jit_info as a dict."""
         info, err = _capi.JitInfo(), C.create_string_buffer(1 << 16)
-        rc = self._L.eu_scene_jit_precompile(self._scene, cache_dir.encode() if cache_dir else None, C.byref(info), err, len(err))
+        rc = self._L.eu_scene_jit_precompile_opts(self._scene, cache_dir.encode() if cache_dir else None, jit_flags.encode() if jit_flags else None, renderer_flags,
+                                                 C.byref(info), err, len(err))
         if rc != _capi.EU_OK:
             raise EuError(rc, err.value.decode())
         return {"from_cache": bool(info.from_cache), "compile_ms": info.compile_ms, "key": info.key.decode(),

@@ -169,15 +169,20 @@ void eu_renderer_destroy(eu_renderer *);
 int eu_renderer_jit_info(eu_renderer *, eu_jit_info *out);
 /* What the most recent failing call on this renderer had to say (valid until the next call on it; "" if nothing failed yet). */
 const char *eu_renderer_error(const eu_renderer *);
-/* Why a renderer that was asked to specialise runs the interpreter kernels (eu_jit_info.active == 0): the scene is beyond the generator's
- * limits (more than 256 shape operations or 48 entities), or the compiler's log; "" when the specialised kernels are in use. */
+/* Why a renderer that was asked to specialise runs the interpreter kernels (eu_jit_info.active == 0): the compiler's log, or what the
+ * runtime said about the code object; "" when the specialised kernels are in use.  (No scene is too large: beyond 256 shape operations
+ * or 48 surfaces the rest of a scene is traced from the flat scene inside the specialised kernels.) */
 const char *eu_renderer_jit_log(const eu_renderer *);
 /* The HIP source eu_renderer_create_opts(EU_SPECIALIZE_SYNC) would compile for this scene (no GPU needed): *source is allocated
  * with eu_alloc, NUL-terminated; free it with eu_free.  key (optional, >= 40 bytes): the cache key. */
 int eu_scene_jit_source(const eu_scene *, char **source, char *key);
+/* The same for a renderer created with eu_renderer_opts.jit_flags / .flags (EU_RENDERER_NO_FUSE selects the two-kernel set): both are
+ * part of the cache key. */
+int eu_scene_jit_source_opts(const eu_scene *, const char *jit_flags, unsigned renderer_flags, char **source, char *key);
 /* Compiles that source for gfx950 into the cache directory without touching a GPU (what a build step runs so that the first
  * renderer does not wait); err receives the compiler's log on failure. */
 int eu_scene_jit_precompile(const eu_scene *, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen);
+int eu_scene_jit_precompile_opts(const eu_scene *, const char *cache_dir, const char *jit_flags, unsigned renderer_flags, eu_jit_info *info, char *err, size_t errlen);
 
 /* Environment::render on the GPU, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
  * rgba_dev: DEVICE buffer of eu_frame_local_rows()*width uint32 (R | G<<8 | B<<16 | 255<<24), rows in

@@ -50,13 +50,10 @@ def kernel_path(request):
     environment.DEFAULT_RENDERER_OPTS["specialize"] = "sync" if mode == "jit" else "off"
     if mode == "jit":
         # a failed compilation falls back to the interpreter kernels BY DESIGN: without this check every test of the specialised
-        # pass would then pass vacuously.  Only a scene beyond the generator's limits (jit.hpp) may run on the interpreter here.
+        # pass would then pass vacuously.  (No scene is too large to specialise: jit.hpp's budgets.)
         def must_be_specialised(env, info):
-            if info["active"]:
-                return
-            if env.info.n_shape_ops > 256 or env.info.n_entities > 48:
-                pytest.skip("scene beyond the specialiser's limits (%d shape ops, %d entities): interpreter kernels" % (env.info.n_shape_ops, env.info.n_entities))
-            raise AssertionError("specialised pass, but this renderer runs the interpreter kernels: %r" % (info,))
+            if not info["active"]:
+                raise AssertionError("specialised pass, but this renderer runs the interpreter kernels: %r" % (info,))
         environment.DEFAULT_RENDERER_OPTS["on_specialize"] = must_be_specialised
     try:
         yield mode

@@ -88,6 +88,33 @@ def test_sequence_and_trace_screen_point_on_specialised_kernels(scene, depth):
     b.close()
 
 
+@pytest.mark.parametrize("scene,depth,flags", [
+    ("3d_room.json", 8, "-DEU_JIT_OPS_BUDGET=3 -DEU_JIT_SURFACES_BUDGET=2"),          # entities 0-2 with code of their own, 3-7 from the flat scene; two surfaces of five
+    ("3d_hallways.json", 12, "-DEU_JIT_OPS_BUDGET=0 -DEU_JIT_SURFACES_BUDGET=0"),     # nothing but the kernels' structure is specialised (LinearSpace expressions stay arithmetic)
+    ("4d_cylinders.json", 5, "-DEU_JIT_OPS_BUDGET=80 -DEU_JIT_SURFACES_BUDGET=4"),    # 15 + 29 + 29 operations fit; the private hit stack
+    ("3d_room.json", 8, "-DEU_JIT_OPS_BUDGET=256 -DEU_JIT_SURFACES_BUDGET=1"),        # every shape, one surface
+])
+def test_mixed_kernels_of_scenes_beyond_the_budgets(scene, depth, flags, tmp_path):
+    """jit.hpp's budgets, forced small: entities and surfaces without code of their own are traced and shaded by the interpreter's routines
+    inside the specialised kernels.  Frames, counters and single pixels equal the interpreter kernels'."""
+    from euclider_amd import Parser
+    path = os.path.join(SCENES, scene)
+    a = Parser().parse_file(path).configure(specialize="off")
+    a.camera.max_depth = depth
+    ref = a.render((256, 144), time=0.75)
+    pts = [a.trace_screen_point(0.75, depth, x, y, 256, 144) for (x, y) in ((3, 3), (128, 72), (200, 40))]
+    a.close()
+    for rflags in ((0, 2) if "BUDGET=3 " in flags else (0,)):          # the fused kernels and, once, the two-kernel pipeline (EU_RENDERER_NO_FUSE)
+        b = Parser().parse_file(path).configure(specialize="sync", jit_flags=flags, cache_dir=str(tmp_path), flags=rflags)
+        b.camera.max_depth = depth
+        img = b.render((256, 144), time=0.75)
+        info = b.jit_info()
+        assert info["active"] and not info["from_cache"], info
+        assert np.array_equal(img.data, ref.data) and img.stats == ref.stats
+        assert [b.trace_screen_point(0.75, depth, x, y, 256, 144) for (x, y) in ((3, 3), (128, 72), (200, 40))] == pts
+        b.close()
+
+
 def test_asynchronous_specialisation(tmp_path):
     """EU_SPECIALIZE_ASYNC: the renderer is usable at once (interpreter kernels), switches to the specialised kernels at a frame boundary
     when the worker thread's compilation is done, and every frame on either side of the switch is the same."""

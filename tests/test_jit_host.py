@@ -1,6 +1,6 @@
 """Scene-specialised kernels, host side (no GPU): the generator (csrc/jit.cpp) on every shipped scene and both precisions, a real hiprtc
-compilation for gfx950 (hiprtc cross-compiles without a device), the code-object cache, and the size limit beyond which a
-renderer keeps the interpreter kernels."""
+compilation for gfx950 (hiprtc cross-compiles without a device), the code-object cache, and the budgets beyond which the rest of a
+scene is traced from the flat scene inside the specialised kernels."""
 import glob
 import os
 import sys
@@ -60,15 +60,51 @@ def test_hiprtc_compile_and_cache(tmp_path):
     env.close()
 
 
-def test_large_scenes_are_not_specialised(tmp_path):
+def test_large_scenes_get_mixed_kernels():
+    """Beyond the generator's budgets (jit.hpp: 256 shape operations, 48 surfaces) a scene's remaining entities and surfaces are traced and
+    shaded from the flat scene INSIDE the specialised kernels, at their place in the entity order (rounds 2-3 left such a scene to the
+    interpreter kernels altogether)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import re
     from random_scenes import random_scene
     from euclider_amd import Parser
-    from euclider_amd.environment import EuError
     text, _ = random_scene(501, n_entities=150)
     env = Parser(texture_dirs=[ROOT]).parse(text)
-    assert env.info.n_entities > 48
-    with pytest.raises(EuError) as ei:
-        env.jit_precompile(str(tmp_path))
-    assert ei.value.code == -5 and "too large" in str(ei.value)
+    assert env.info.n_entities > 48 and env.info.n_shape_ops > 256
+    src, key = env.jit_source()
     env.close()
+    runs = [(int(a), int(b)) for a, b in re.findall(r"interp_entities<\d>\(S, (\d+)u, (\d+)u,", src)]
+    assert runs and all(a < b for a, b in runs) and runs == sorted(runs)
+    own = [int(e) for e in re.findall(r"/\* entity (\d+): ops", src)]
+    assert own and not any(a <= e < b for e in own for a, b in runs)          # every entity is traced once: by its own code or by a run
+    assert "material_at_range<" in src and "::hit_normal<" in src and "surface_color<" in src
+    assert src.count("static EU_DEV void surf_") == 48
+
+
+def test_budgets_are_part_of_the_key_and_the_mixed_kernels_compile(tmp_path):
+    from euclider_amd import Parser
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", "3d_room.json"))
+    whole, key = env.jit_source()
+    assert "interp_entities" not in whole and "surface_color<" not in whole
+    flags = "-DEU_JIT_OPS_BUDGET=3 -DEU_JIT_SURFACES_BUDGET=2"
+    mixed, key2 = env.jit_source(flags)
+    assert key2 != key
+    assert "interp_entities<3>(S, 3u, 8u," in mixed and "material_at_range<3>(S, 3u, 8u, p)" in mixed and mixed.count("static EU_DEV void surf_") == 2
+    info = env.jit_precompile(str(tmp_path), flags)
+    assert info["key"] == key2 and not info["from_cache"]
+    env.close()
+
+
+def test_congruent_entities_get_one_body():
+    """4d_cylinders: entities 1..8 are the same 29 operations on parameters a constant stride apart: one body in a loop over them (jit.cpp:
+    find_runs), a quarter of the source of the straight-line form (-DEU_JIT_NO_RUNS, which rounds 2-3 emitted)."""
+    from euclider_amd import Parser
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", "4d_cylinders.json"))
+    src, key = env.jit_source()
+    flat, key2 = env.jit_source("-DEU_JIT_NO_RUNS")
+    env.close()
+    assert key != key2
+    assert "for (uint32_t ge = 0; ge < 8u; ge++) {   /* entities 1..8: congruent, ops 15..43 each */" in src
+    assert "const uint32_t po = ge * 126u, bo = ge * 30u, oo = ge * 29u;" in src
+    assert "ge++" not in flat and flat.count("/* entity ") == 9 and src.count("/* entity ") == 1
+    assert len(src) * 3 < len(flat)

@@ -1,4 +1,4 @@
-"""Diagnostic: frame pipeline time for tiny frames = the fixed cost of its launches.  Usage: python tools/fixed_cost.py [sync|off] [scene depth]"""
+"""Diagnostic: frame pipeline time for tiny frames = the fixed cost of its launches.  Usage: python tools/fixed_cost.py [sync|off] [scene depth [wavefront|stack]]"""
 import os
 import sys
 
@@ -8,10 +8,11 @@ from euclider_amd import Parser  # noqa: E402
 
 spec = sys.argv[1] if len(sys.argv) > 1 else "sync"
 scene = sys.argv[2] if len(sys.argv) > 2 else "3d_room.json"
-env = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize=spec)
+kernel = sys.argv[4] if len(sys.argv) > 4 else None
+env = Parser().parse_file(os.path.join(ROOT, "scenes", scene)).configure(specialize=spec, kernel=kernel)
 env.camera.max_depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-print(scene, "depth", env.camera.max_depth, "specialize", spec)
-for w, h in ((64, 64), (256, 256), (640, 360), (960, 540), (1920, 1080)):
+print(scene, "depth", env.camera.max_depth, "specialize", spec, "kernel", kernel or "default")
+for w, h in ((64, 64), (128, 96), (256, 256), (640, 360), (960, 540), (1920, 1080)):
     for _ in range(5):
         img = env.render((w, h))
     ms = env.kernel_ms_history(4)

@@ -17,7 +17,8 @@ w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 h = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 env = Parser().parse_file(os.path.join(ROOT, "scenes", scene))
 if os.environ.get("EU_PROFILE_JIT"):
-    env.configure(specialize="sync", jit_flags="-DEU_PROFILE_SHADE_WAVE" if os.environ.get("EU_PROFILE_KERNEL") == "shade" else "-DEU_PROFILE_SHAPE")
+    env.configure(specialize="sync", jit_flags=("-DEU_PROFILE_SHADE_WAVE" if os.environ.get("EU_PROFILE_KERNEL") == "shade" else "-DEU_PROFILE_SHAPE") +
+                  (" -DEU_PROFILE_SHAPE_LANES" if os.environ.get("EU_PROFILE_LANES") else ""))      # EU_PROFILE_LANES=1: every share weighted with the lanes active at its stamp (x / 64)
 env.camera.max_depth = depth
 img = env.render((w, h))
 ph = (C.c_uint64 * 16)()
@@ -30,7 +31,7 @@ names = ["chain: bound test, set-up", "chain: matrices (t_k, IN, LT)", "chain: m
 if os.environ.get("EU_PROFILE_KERNEL") == "shade":      # -DEU_PROFILE_SHADE_WAVE build: sections of eu_wf_shade_kernel
     names = ["(live test)", "ray + hit loaded, hit point, normal, angle (HitCtx)", "surface record, reflection ratio (Fresnel)", "transmission set-up outside the parts below",
              "reflection direction, node record, delivery of a finished colour", "children that only sample the background", "children appended to the next queue", "-",
-             "surface colour program", "to_pixel of the surface colour", "threshold direction (Snell: rotation)", "child origin, material_at of an exiting ray", "-", "-", "-",
+             "surface colour program", "to_pixel of the surface colour", "threshold direction (Snell: rotation)", "child origin, material_at of an exiting ray", "fused part: trace_closest of a batch of own children", "barrier before the fused part", "fused part: waiting for the last batch",
              "window sort, batch loop, kernel prologue / epilogue"]
     tot = float(sum(ph[:16])) or 1.0
     for i in range(16):
