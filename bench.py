@@ -338,8 +338,8 @@ def other_configs(torch, dev, Parser, args, in_flight):
             e.configure(specialize=args.specialize, streams=args.streams or (1 if R > 1 else 0), jit_flags=args.jit_flags, flags=args.renderer_flags)
             e.camera.max_depth = depth
             envs.append(e)
-            if len(envs) == 1 and R > 5 and e.jit_info(device=dev.index)["hit_stack_entries"] > 24:
-                R = 5      # a scene whose hit stack lives in scratch (more than 24 entries per ray): eight frames' scratch compete for the L2 (4d_cylinders: 4.9 against 4.5 Gray/s)
+            # (round 3 kept five frames in flight for a scene whose hit stack lives in scratch -- 4d_cylinders' straight-line kernels with their
+            # 1 300 spilled SGPRs: 4.9 against 4.5 Gray/s; with one loop body per run of congruent entities eight are better: 5.6 against 5.4)
         env = envs[0]
         frame = env.frame(W, H, time=0.0, rows=(0, H))
         streams = [torch.cuda.Stream(dev) for _ in range(R)]
