@@ -88,7 +88,7 @@ extern "C" int eu_scene_jit_precompile_opts(const eu_scene *scene, const char *c
         info->requested = 1; info->from_cache = b.from_cache ? 1 : 0; info->hit_stack_entries = plan.hs_cap; info->compile_ms = b.compile_ms;
         snprintf(info->key, sizeof info->key, "%s", plan.key.c_str());
     }
-    if (rc != EU_OK) set_err(err, errlen, b.log);
+    if (rc != EU_OK || !b.log.empty()) set_err(err, errlen, b.log);      /* (on success: the compiler's warnings and the generator's notes, if any) */
     return rc;
 }
 extern "C" int eu_scene_jit_precompile(const eu_scene *scene, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen) {

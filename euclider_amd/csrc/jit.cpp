@@ -26,7 +26,7 @@
 
 namespace euclider {
 
-#define EU_JIT_VERSION "eu-jit-5"
+#define EU_JIT_VERSION "eu-jit-6"
 
 /* the device headers, embedded at build time (csrc/Makefile: jit_headers.inc) */
 struct EmbeddedHeader { const char *name; const char *text; };
@@ -700,7 +700,8 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags, bool
            "    wf_shade_body<%d, false, EuJit, true>(scene_g, scene_words, 0u, cam.max_depth, fr.time_s, cam, fr, B, counters, rgba, hit_t_aov, point_rgb, lds_dyn);\n}\n", plan.dim);
     } else {
     /* the fused forms: shade generation g, then intersect the rays just queued (trace_wavefront.h: FUSE) */
-    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_fshade(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t max_depth, real time_s,\n"
+    tail.f("#ifndef EU_FSHADE_WAVES\n#define EU_FSHADE_WAVES EU_SHADE_WAVES\n#endif\n");
+    tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_FSHADE_WAVES) void eu_jit_fshade(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, uint32_t gen, uint32_t max_depth, real time_s,\n"
            "        EuWfBuffers B, EuDevCounters *counters, uint32_t *__restrict__ rgba, eu_f64 *__restrict__ point_rgb) {\n    extern __shared__ uint64_t lds_dyn[];\n    const EuDevCamera cam = {};\n    const EuDevFrame fr = {};\n"
            "    wf_shade_body<%d, false, EuJit, false, %u>(scene_g, scene_words, gen, max_depth, time_s, cam, fr, B, counters, rgba, nullptr, point_rgb, lds_dyn, hs_cap);\n}\n\n", plan.dim, hscap);
     tail.f("extern \"C\" __global__ __launch_bounds__(EU_WF_BLOCK, EU_SHADE_WAVES) void eu_jit_fshade0(const uint64_t *__restrict__ scene_g, uint32_t scene_words, uint32_t hs_cap, EuDevCamera cam, EuDevFrame fr,\n"
@@ -775,6 +776,56 @@ static std::string library_cache_dir() {      /* <directory of this shared libra
     return std::string();
 }
 
+/* one hiprtc compilation of the plan's source (extra: one more flag, or nullptr) */
+static int hiprtc_compile(const JitPlan &plan, const char *extra, std::vector<char> &code, std::string &log) {
+    hiprtcProgram prog = nullptr;
+    std::vector<const char *> hdr_text, hdr_name;
+    for (int k = 0; k < kNumHeaders; k++) { hdr_text.push_back(kHeaders[k].text); hdr_name.push_back(kHeaders[k].name); }
+    hiprtcResult rc = hiprtcCreateProgram(&prog, plan.source.c_str(), "eu_jit_scene.hip", kNumHeaders, hdr_text.data(), hdr_name.data());
+    if (rc != HIPRTC_SUCCESS) { log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
+    std::vector<const char *> flags(kCompileFlags, kCompileFlags + sizeof(kCompileFlags) / sizeof(kCompileFlags[0]));
+    for (const std::string &f : plan.extra_flags) flags.push_back(f.c_str());
+    if (extra) flags.push_back(extra);
+    rc = hiprtcCompileProgram(prog, (int)flags.size(), flags.data());
+    size_t log_size = 0;
+    if (hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1) {
+        log.resize(log_size);
+        (void)hiprtcGetProgramLog(prog, &log[0]);
+    }
+    if (rc != HIPRTC_SUCCESS) {
+        log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(rc) + "\n" + log;
+        (void)hiprtcDestroyProgram(&prog);
+        return EU_ERR_HIP;
+    }
+    size_t code_size = 0;
+    rc = hiprtcGetCodeSize(prog, &code_size);
+    if (rc == HIPRTC_SUCCESS) { code.resize(code_size); rc = hiprtcGetCode(prog, code.data()); }
+    (void)hiprtcDestroyProgram(&prog);
+    if (rc != HIPRTC_SUCCESS || code_size == 0) { log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
+    return EU_OK;
+}
+
+/* A count out of a code object's metadata (the NT_AMDGPU_METADATA note: MessagePack, every kernel a map with its keys in alphabetical
+ * order, ".name" before ".vgpr_count" and ".vgpr_spill_count"): the value of `key` in the map of kernel `kernel`; -1 if not found.
+ * (Not a MessagePack reader: the byte patterns of "key: string" and "key: small unsigned" are looked for, which is all it is used for.) */
+static int code_object_count(const std::vector<char> &code, const char *kernel, const char *key) {
+    auto str = [](const char *t) { std::string o; const size_t n = strlen(t); o.push_back((char)(n < 32 ? 0xa0 + n : 0xd9)); if (n >= 32) o.push_back((char)n); o += t; return o; };
+    const std::string name = str(".name") + str(kernel), want = str(key), next_kernel = str(".name");
+    const std::string blob(code.begin(), code.end());
+    const size_t at = blob.find(name);
+    if (at == std::string::npos) return -1;
+    const size_t end = blob.find(next_kernel, at + name.size());
+    const size_t k = blob.find(want, at + name.size());
+    if (k == std::string::npos || (end != std::string::npos && k > end)) return -1;
+    const size_t p = k + want.size();
+    if (p >= blob.size()) return -1;
+    const unsigned char b = (unsigned char)blob[p];
+    if (b < 0x80) return (int)b;
+    if (b == 0xcc && p + 1 < blob.size()) return (int)(unsigned char)blob[p + 1];
+    if (b == 0xcd && p + 2 < blob.size()) return (int)(((unsigned)(unsigned char)blob[p + 1] << 8) | (unsigned char)blob[p + 2]);
+    return -1;
+}
+
 int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &out, bool cache_only) {
 #if EU_REAL_BITS == 32
     const std::string fname = plan.key + "_f32.hsaco";
@@ -801,29 +852,29 @@ int jit_build(const JitPlan &plan, const std::string &cache_dir_in, JitBuild &ou
     }
     if (cache_only) { out.log = "not in any cache"; return EU_ERR_BUSY; }
     const auto t0 = std::chrono::steady_clock::now();
-    hiprtcProgram prog = nullptr;
-    std::vector<const char *> hdr_text, hdr_name;
-    for (int k = 0; k < kNumHeaders; k++) { hdr_text.push_back(kHeaders[k].text); hdr_name.push_back(kHeaders[k].name); }
-    hiprtcResult rc = hiprtcCreateProgram(&prog, plan.source.c_str(), "eu_jit_scene.hip", kNumHeaders, hdr_text.data(), hdr_name.data());
-    if (rc != HIPRTC_SUCCESS) { out.log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
-    std::vector<const char *> flags(kCompileFlags, kCompileFlags + sizeof(kCompileFlags) / sizeof(kCompileFlags[0]));
-    for (const std::string &f : plan.extra_flags) flags.push_back(f.c_str());
-    rc = hiprtcCompileProgram(prog, (int)flags.size(), flags.data());
-    size_t log_size = 0;
-    if (hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1) {
-        out.log.resize(log_size);
-        (void)hiprtcGetProgramLog(prog, &out.log[0]);
+    int rc0 = hiprtc_compile(plan, nullptr, out.code, out.log);
+    if (rc0 != EU_OK) return rc0;
+    /* The fused shade kernel lives at a register cliff: at 128 VGPRs four of its waves share a SIMD, at 129 three (3d_room: 1.31 against 1.43 ms
+     * per frame), and where the allocator lands depends on details of the scene's code.  When it lands just above, the kernel is compiled again
+     * with launch bounds of four waves; that object is kept if it spills next to nothing (3d_room then: 128 VGPRs, 3 spilled, as fast as a
+     * natural 127).  Kernels far above (the 4-D scenes' 150) are left alone: forced to 128 they spill 60-80 registers and lose 3 %. */
+    if (plan.fused) {
+        bool given = false;
+        for (const std::string &f : plan.extra_flags) given = given || f.rfind("-DEU_FSHADE_WAVES=", 0) == 0 || f.rfind("-DEU_SHADE_WAVES=", 0) == 0;
+        int lo = 128;      /* (tests: -DEU_JIT_CLIFF_LO=100 makes every scene's kernel count as "just above") */
+        for (const std::string &f : plan.extra_flags) if (f.rfind("-DEU_JIT_CLIFF_LO=", 0) == 0) lo = atoi(f.c_str() + 18);
+        const int v = given ? -1 : code_object_count(out.code, "eu_jit_fshade", ".vgpr_count");
+        if (v > lo && v <= 136) {
+            std::vector<char> code4; std::string log4;
+            if (hiprtc_compile(plan, "-DEU_FSHADE_WAVES=4", code4, log4) == EU_OK) {
+                const int v4 = code_object_count(code4, "eu_jit_fshade", ".vgpr_count"), s4 = code_object_count(code4, "eu_jit_fshade", ".vgpr_spill_count");
+                if (v4 > 0 && v4 <= 128 && s4 >= 0 && s4 <= 8) {
+                    out.code.swap(code4);
+                    out.log += "\neu_jit_fshade: " + std::to_string(v) + " VGPRs -> compiled for four waves per SIMD (" + std::to_string(v4) + " VGPRs, " + std::to_string(s4) + " spilled)";
+                }
+            }
+        }
     }
-    if (rc != HIPRTC_SUCCESS) {
-        out.log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(rc) + "\n" + out.log;
-        (void)hiprtcDestroyProgram(&prog);
-        return EU_ERR_HIP;
-    }
-    size_t code_size = 0;
-    rc = hiprtcGetCodeSize(prog, &code_size);
-    if (rc == HIPRTC_SUCCESS) { out.code.resize(code_size); rc = hiprtcGetCode(prog, out.code.data()); }
-    (void)hiprtcDestroyProgram(&prog);
-    if (rc != HIPRTC_SUCCESS || code_size == 0) { out.log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(rc); return EU_ERR_HIP; }
     out.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out.from_cache = false;
     if (!user_dir.empty()) {   /* keep it: atomically, so that a concurrent reader never sees half a file */

@@ -170,7 +170,7 @@ class Environment:
         if rc != _capi.EU_OK:
             raise EuError(rc, err.value.decode())
         return {"from_cache": bool(info.from_cache), "compile_ms": info.compile_ms, "key": info.key.decode(),
-                "hit_stack_entries": info.hit_stack_entries}
+                "hit_stack_entries": info.hit_stack_entries, "log": err.value.decode(errors="replace")}
 
     # -- Environment trait
     def max_depth(self):

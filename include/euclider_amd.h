@@ -180,7 +180,7 @@ int eu_scene_jit_source(const eu_scene *, char **source, char *key);
  * part of the cache key. */
 int eu_scene_jit_source_opts(const eu_scene *, const char *jit_flags, unsigned renderer_flags, char **source, char *key);
 /* Compiles that source for gfx950 into the cache directory without touching a GPU (what a build step runs so that the first
- * renderer does not wait); err receives the compiler's log on failure. */
+ * renderer does not wait); err receives the compiler's log on failure (on success: its warnings and the generator's notes, or ""). */
 int eu_scene_jit_precompile(const eu_scene *, const char *cache_dir, eu_jit_info *info, char *err, size_t errlen);
 int eu_scene_jit_precompile_opts(const eu_scene *, const char *cache_dir, const char *jit_flags, unsigned renderer_flags, eu_jit_info *info, char *err, size_t errlen);
 

@@ -108,3 +108,15 @@ def test_congruent_entities_get_one_body():
     assert "const uint32_t po = ge * 126u, bo = ge * 30u, oo = ge * 29u;" in src
     assert "ge++" not in flat and flat.count("/* entity ") == 9 and src.count("/* entity ") == 1
     assert len(src) * 3 < len(flat)
+
+
+def test_guard_at_the_register_cliff(tmp_path):
+    """jit_build reads the fused shade kernel's register count from the code object's metadata and, just above 128 (four waves per SIMD -> three),
+    compiles the module again with launch bounds of four waves.  -DEU_JIT_CLIFF_LO=100 makes 3d_fresnel's kernel count as "just above"."""
+    from euclider_amd import Parser
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", "3d_fresnel.json"))
+    plain = env.jit_precompile(str(tmp_path / "a"))
+    forced = env.jit_precompile(str(tmp_path / "b"), "-DEU_JIT_CLIFF_LO=100")
+    env.close()
+    assert "four waves" not in plain["log"]
+    assert "eu_jit_fshade: " in forced["log"] and "compiled for four waves per SIMD" in forced["log"], forced["log"]
