@@ -302,16 +302,18 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def other_configs(torch, dev, Parser, args, in_flight):
-    """BASELINE.json configs 3 and 4, the extra 4-D scene, the 8K frame on one GPU, the reference's own depth and the f32 build: a few
-    steps each, so that the driver's record carries them too.  Same timing rule as the headline (device-resident, synchronised on both
-    sides, the same number of frames in flight; two for the 8K frame, whose bands are 4 Mpixel each)."""
-    out = []
-    for scene, W, H, depth, steps, lp in (("3d_hallways.json", 1920, 1080, 12, 40, False), ("4d_frame.json", 1920, 1080, 8, 40, False),
-                                          ("4d_cylinders.json", 1920, 1080, 8, 32, False), ("3d_room.json", 7680, 4320, 8, 6, False),
-                                          ("3d_room.json", 1920, 1080, 10, 40, False), ("3d_room.json", 1920, 1080, 8, 40, True)):
-        R = min(in_flight, 2) if W * H > (4 << 20) else in_flight
-        # one frame at a time on a renderer with the library's defaults (the reference's call shape), before the slots' renderers exist
+OTHER_CONFIGS = (("3d_hallways.json", 1920, 1080, 12, 40, False), ("4d_frame.json", 1920, 1080, 8, 40, False),
+                 ("4d_cylinders.json", 1920, 1080, 8, 32, False), ("3d_room.json", 7680, 4320, 8, 6, False),
+                 ("3d_room.json", 1920, 1080, 10, 40, False), ("3d_room.json", 1920, 1080, 8, 40, True))
+
+
+def other_configs_alone(torch, dev, Parser, args):
+    """ONE frame at a time for each of the other configurations, on a renderer with the library's defaults (the reference's call shape) -- all of
+    them measured before any of the pipelined runs' renderers and streams exist: which hardware queues a renderer's band streams get depends on
+    what the process has created before (a record of this round had these numbers 20-50 % apart between two runs that differed in how many
+    renderers an EARLIER configuration had kept alive)."""
+    res = []
+    for scene, W, H, depth, steps, lp in OTHER_CONFIGS:
         ea = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
         ea.configure(specialize=args.specialize, streams=args.streams, jit_flags=args.jit_flags, flags=args.renderer_flags)
         ea.camera.max_depth = depth
@@ -329,9 +331,19 @@ def other_configs(torch, dev, Parser, args, in_flight):
             if k >= 2:
                 ts.append((time.perf_counter() - t1) * 1e3)
         ts.sort()
-        alone_kms = ea.kernel_ms_history(4, device=dev.index)
+        res.append((ts, ea.kernel_ms_history(4, device=dev.index)))
         ea.close()
         del rgba0, rgb0
+    return res
+
+
+def other_configs(torch, dev, Parser, args, in_flight, alone_results):
+    """BASELINE.json configs 3 and 4, the extra 4-D scene, the 8K frame on one GPU, the reference's own depth and the f32 build: a few
+    steps each, so that the driver's record carries them too.  Same timing rule as the headline (device-resident, synchronised on both
+    sides, the same number of frames in flight; two for the 8K frame, whose bands are 4 Mpixel each)."""
+    out = []
+    for (scene, W, H, depth, steps, lp), (ts, alone_kms) in zip(OTHER_CONFIGS, alone_results):
+        R = min(in_flight, 2) if W * H > (4 << 20) else in_flight
         envs = []
         while len(envs) < R:
             e = Parser(low_precision=lp).parse_file(os.path.join(ROOT, "scenes", scene))
@@ -587,6 +599,9 @@ def main():
         alone_rgb = rgb1[:H * W * 3].clone()
         ea.close()
         del rgba1, rgb1
+    others_alone = None
+    if world == 1 and not args.no_other_configs and not args.fixed_frame and args.scene == "3d_room.json" and not args.low_precision:
+        others_alone = other_configs_alone(torch, dev, Parser, args)
 
     run = timed_run(W, H, args.steps, args.warmup, in_flight, args.repeats)
     elapsed, rays_per_step, st, kms, local_rows, rgb_out = run["elapsed"], run["rays"], run["st"], run["kms"], run["local_rows"], run["rgb_out"]
@@ -676,7 +691,7 @@ def main():
             for e in envs:      # (their streams would share hardware queues with the next renderers' band streams)
                 e.close()
             del envs[:]
-            out["other_configs"] = other_configs(torch, dev, Parser, args, in_flight)
+            out["other_configs"] = other_configs(torch, dev, Parser, args, in_flight, others_alone)
         print(json.dumps(out), flush=True)
         if out.get("parity", {}).get("mismatch") or not out["config"]["slots_agree"]:
             parity_failed = True
