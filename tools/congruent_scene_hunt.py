@@ -1,6 +1,6 @@
 """Differential hunt for the generator's runs of congruent entities (jit.cpp: find_runs): rows of entities with the same random shape program at
 different places, other entities between them, random surfaces and cameras; specialised kernels against the oracle, bit for bit.
-Usage: python tools/congruent_scene_hunt.py <first seed> <last seed>"""
+Usage: [HUNT_F32=1] python tools/congruent_scene_hunt.py <first seed> <last seed>"""
 import json
 import os
 import random
@@ -87,12 +87,13 @@ def scene(seed):
 
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+F32 = os.environ.get("HUNT_F32") == "1"      # the low_precision pair: libeuclider_amd_f32.so against libeo_oracle_f32.so
 bad, loops, skipped, undefined = [], 0, 0, 0
 for seed in range(lo, hi):
     text, cam = scene(seed)
     try:
-        osc = OracleScene(text, default_texture_loader([ROOT]))
-        env = Parser(texture_dirs=[ROOT]).parse(text).configure(specialize="sync")
+        osc = OracleScene(text, default_texture_loader([ROOT]), variant="f32" if F32 else "")
+        env = Parser(texture_dirs=[ROOT], low_precision=F32).parse(text).configure(specialize="sync")
     except Exception:
         skipped += 1
         continue
@@ -118,6 +119,6 @@ for seed in range(lo, hi):
     if not active or not np.array_equal(img.data, orgb) or img.stats != ost:
         bad.append((seed, active, int((img.data != orgb).sum()), img.stats, ost))
     print("seed", seed, "loops so far", loops, "bad", len(bad), flush=True)
-print("congruent-entity hunt: seeds", lo, hi, "loop bodies emitted", loops, "bad", len(bad), "undefined", undefined, "skipped", skipped)
+print("congruent-entity hunt:", "f32" if F32 else "f64", "seeds", lo, hi, "loop bodies emitted", loops, "bad", len(bad), "undefined", undefined, "skipped", skipped)
 for b in bad[:10]:
     print(b)
