@@ -270,12 +270,76 @@ struct Gen {
         }
     }
 
+    /* A LEFT FOLD of congruent operands inside one shape program -- X1 X2 M X3 M ... Xk M, every X one leaf or chain of the same kind with its
+     * parameters a constant stride after the one before, every M the same operation on (everything so far, X) -- is what ComposableShape::of
+     * makes of a list (shape.rs:523-545): 4d_frame's four inner boxes, a union of spheres.  It gets ONE push and ONE merge in a loop over the
+     * operands from the second on; the containment test of "everything so far" is the fold of the operands' tests in the same order.
+     * Returns the number of operands (0: no such fold at op i), `stride` = reals between two operands' parameters. */
+    bool no_folds = false;      /* tuning / tests: -DEU_JIT_NO_FOLDS */
+    uint32_t fold_len(uint32_t i, uint32_t last, uint32_t root, uint32_t &stride) const {
+        if (no_folds || !shape_params_in_memory || i + 2 > last) return 0;
+        const OpView x1 = op(i), x2 = op(i + 1), m1 = op(i + 2);
+        auto single = [](const OpView &x) { return x.kind != EU_SH_SKIP && x.kind != EU_SH_VOID && (x.kind < EU_SH_UNION || x.kind >= EU_SH_CHAIN_UNION); };
+        auto merge = [](const OpView &m) { return m.kind >= EU_SH_UNION && m.kind < EU_SH_CHAIN_UNION; };
+        if (!single(x1) || !single(x2) || !merge(m1) || x2.kind != x1.kind || x2.count != x1.count || x2.param <= x1.param) return 0;
+        if (m1.first != i || m1.count != 0 || i + 2 >= root) return 0;
+        stride = x2.param - x1.param;
+        uint32_t k = 2, at = i + 3;      /* operands so far; the op after the last merge */
+        while (at + 1 <= last && at + 1 < root) {
+            const OpView x = op(at), m = op(at + 1);
+            if (!single(x) || x.kind != x1.kind || x.count != x1.count || x.param != x1.param + k * stride) break;
+            if (!merge(m) || m.kind != m1.kind || m.first != i || m.count != 0) break;
+            k++; at += 2;
+        }
+        return k >= 3 ? k : 0;
+    }
+    std::string fold_fns;      /* static member functions of the folds: the operands' containment tests */
+    void emit_fold(Out &d, uint32_t i, uint32_t k, uint32_t stride, std::vector<std::string> &st, const std::string &ind) {
+        const OpView x1 = op(i), m1 = op(i + 2);
+        const bool chain = x1.kind >= EU_SH_CHAIN_UNION;
+        /* fin_<i>(S, p, j, po): operand j contains p;  fin_acc_<i>(S, p, n, po): the fold of operands 0..n-1 does (shape.rs:589-600, left to right) */
+        {
+            Out f;
+            f.f("    static EU_DEV bool fin_%u(const EuScene &S, const real *p, uint32_t j, uint32_t po) {\n"
+                "        const real *const P = (const real *)(S.w + %uu) + (%uu + j * %uu + po);\n", i, h->off_params, x1.param, stride);
+            if (x1.kind == EU_SH_CHAIN_BOX) f.f("        return chain_inside_box<%d>(P, p);\n", D);
+            else if (x1.kind == EU_SH_CHAIN_BOX0 && D == 3) f.f("        return chain_inside_box<%d, true>(P, p);\n", D);
+            else if (chain) f.f("        return chain_inside<%d>(%s, %uu, P, p);\n", D, x1.kind == EU_SH_CHAIN_UNION ? "true" : "false", x1.count);
+            else f.f("        return leaf_inside<%d>(%s, P, p);\n", D, kind_name(x1.kind));
+            const char *acc = m1.kind == EU_SH_UNION ? "r = (r | b);" : m1.kind == EU_SH_INTERSECTION ? "r = (r & b);" : m1.kind == EU_SH_COMPLEMENT ? "r = (r & !b);" : "r = (r ^ b);";
+            f.f("    }\n    static EU_DEV bool fin_acc_%u(const EuScene &S, const real *p, uint32_t n, uint32_t po) {\n"
+                "        bool r = fin_%u(S, p, 0u, po);\n        _Pragma(\"nounroll\") for (uint32_t j = 1; j < n; j++) { const bool b = fin_%u(S, p, j, po); %s }\n        return r;\n    }\n", i, i, i, acc);
+            fold_fns += f.s;
+        }
+        char acc[32];
+        snprintf(acc, sizeof acc, "LF%u", i);
+        const char *push = chain ? "push_chain" : "push_leaf";
+        /* operand 0, then operands 1..k-1 in a loop: operand j >= 1 is op i + 2 j - 1 */
+        if (chain) d.f("%sCsgList %s; { %s %s = push_chain<%d>(%s, %uu, P, o, d, hs, sp, %uu + oo, cnt, use_box, fail); }\n", ind.c_str(), acc, op_params("P", i).c_str(), acc, D, kind_name(x1.kind), x1.count, i);
+        else d.f("%sCsgList %s; { %s %s = push_leaf<%d>(%s, P, o, d, hs, sp, %uu + oo, cnt); }\n", ind.c_str(), acc, op_params("P", i).c_str(), acc, D, kind_name(x1.kind), i);
+        d.f("%s_Pragma(\"nounroll\") for (uint32_t fj = 1; fj < %uu; fj++) {   /* operands 1..%u of the fold that starts at op %u */\n", ind.c_str(), k, k - 1, i);
+        d.f("%s    const real *const P = (const real *)(S.w + %uu) + (%uu + fj * %uu + po);\n", ind.c_str(), h->off_params, x1.param, stride);
+        if (chain) d.f("%s    const CsgList Lb = %s<%d>(%s, %uu, P, o, d, hs, sp, %uu + 2u * fj - 1u + oo, cnt, use_box, fail);\n", ind.c_str(), push, D, kind_name(x1.kind), x1.count, i);
+        else d.f("%s    const CsgList Lb = %s<%d>(%s, P, o, d, hs, sp, %uu + 2u * fj - 1u + oo, cnt);\n", ind.c_str(), push, D, kind_name(x1.kind), i);
+        d.f("%s    %s = csg_merge<%d>(%s, false, hs, sp, %s, Lb, o, d, cnt, [&](const real *q) { return fin_acc_%u(S, q, fj, po); }, [&](const real *q) { return fin_%u(S, q, fj, po); });\n%s}\n",
+            ind.c_str(), acc, D, kind_name(m1.kind), acc, i, i, ind.c_str());
+        st.push_back(acc);
+    }
+
     /* ---- eval_shape of ops[first..last] inside a tree, straight line; `st`: names of the CsgList variables on the hit stack ---- */
     void emit_tree_range(Out &d, uint32_t first, uint32_t last, uint32_t root, std::vector<std::string> &st, const std::string &ind) {
         for (uint32_t i = first; i <= last; i++) {
             const OpView p = op(i);
             char v[32];
             snprintf(v, sizeof v, "L%u", i);
+            {
+                uint32_t stride = 0;
+                if (const uint32_t k = fold_len(i, last, root, stride)) {
+                    emit_fold(d, i, k, stride, st, ind);
+                    i += 2 * k - 2;      /* the fold's last merge is op i + 2 k - 2 */
+                    continue;
+                }
+            }
             if (p.kind == EU_SH_SKIP) {      /* every ray of the wave misses the subtree's sphere -> its stream is empty (eval_shape) */
                 snprintf(v, sizeof v, "LG%u", p.first);
                 d.f("%sCsgList %s = {0u, false, false};\n%s{ %s\n%s  if (__ballot(!ray_misses_bound<%d>(G, o, d)) != 0ull) {\n", ind.c_str(), v, ind.c_str(),
@@ -633,6 +697,7 @@ struct Gen {
 
         o.f("struct EuJit {\n    static constexpr bool kInterpreter = false;\n");
         o.s += inside_defs;      /* (complete by now: every emitter above has registered the subtrees it tests) */
+        o.s += fold_fns;
         o.s += tc.s; o.s += hn.s; o.s += sf.s; o.s += ma.s; o.s += mp.s; o.s += bg.s;
         o.f("};\n\n");
     }
@@ -678,6 +743,7 @@ JitPlan jit_generate(const FlatScene &flat, const std::string &extra_flags, bool
         if (f.rfind("-DEU_JIT_OPS_BUDGET=", 0) == 0) g.ops_budget = (uint32_t)strtoul(f.c_str() + 20, nullptr, 10);
         else if (f.rfind("-DEU_JIT_SURFACES_BUDGET=", 0) == 0) g.surfaces_budget = (uint32_t)strtoul(f.c_str() + 25, nullptr, 10);
         else if (f == "-DEU_JIT_NO_RUNS") g.no_runs = true;
+        else if (f == "-DEU_JIT_NO_FOLDS") g.no_folds = true;
     g.generate();
     plan.n_straight_ops = g.n_straight_ops;
     plan.n_interp_entities = g.n_interp_entities;

@@ -120,3 +120,18 @@ def test_guard_at_the_register_cliff(tmp_path):
     env.close()
     assert "four waves" not in plain["log"]
     assert "eu_jit_fshade: " in forced["log"] and "compiled for four waves per SIMD" in forced["log"], forced["log"]
+
+
+def test_left_folds_of_congruent_operands_get_one_body():
+    """4d_frame's one entity is Complement(box, Union(box, box, box, box)): the Union is a left fold of four congruent chains (ComposableShape::of,
+    shape.rs:523-545) and gets ONE push and ONE merge in a loop over the operands from the second on (jit.cpp: fold_len, emit_fold)."""
+    from euclider_amd import Parser
+    env = Parser().parse_file(os.path.join(ROOT, "scenes", "4d_frame.json"))
+    src, key = env.jit_source()
+    flat, key2 = env.jit_source("-DEU_JIT_NO_FOLDS")
+    env.close()
+    assert key != key2
+    assert "for (uint32_t fj = 1; fj < 4u; fj++) {   /* operands 1..3 of the fold that starts at op 1 */" in src
+    assert "fin_acc_1(S, q, fj, po)" in src and "static EU_DEV bool fin_1(" in src
+    assert src.count("push_chain<4>(") == 3 and flat.count("push_chain<4>(") == 5          # the outer box, the fold's first operand, the loop body
+    assert "fj++" not in flat
