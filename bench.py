@@ -5,12 +5,15 @@ One "step" = one Environment::render pass: every pixel of the frame is traced by
 wavefront pipeline (intersect + shade per generation, resolve; scene, textures and the output frame resident in HBM; by default with
 kernels specialised for the scene, compiled when the renderer is created) and the
 RGBA8 result is packed to the reference's RGB8 RawImage2d layout, also in HBM.  Steps are issued round-robin to `--frames-in-flight`
-renderers (default 8), each with a stream and buffers of its own, so that consecutive frames overlap on the device the way the frame
+renderers (default 12), each with a stream and buffers of its own, so that consecutive frames overlap on the device the way the frame
 loop of the C ABI (eu_sequence_*) overlaps them; the timed region still holds exactly K whole frames between two device
 synchronisations, and `config.one_frame_alone` carries the time of a single frame with nothing else in flight.  The HIP runtime
-maps streams onto GPU_MAX_HW_QUEUES hardware queues (its default: 4); this script asks for 8 -- one per frame in flight -- unless the
-environment already says otherwise, and reports the value in `config.gpu_max_hw_queues` (8 frames on 4 queues: 8.2 Gray/s on config
-2, on 8 queues: 8.9; INTEGRATION.md tells a host how to set it).
+maps streams onto GPU_MAX_HW_QUEUES hardware queues (its default: 4); this script asks for 8 unless the environment already says
+otherwise, and reports the value in `config.gpu_max_hw_queues` (round 4's final kernels on config 2, queues x frames in flight, the
+timed region alone in the process: 8 x 8 8.4-8.5 Gray/s, 8 x 12 9.1, 12 x 12 9.3-9.4, 12 x 16 9.3, 16 x 12 9.2, 24 x 24 7.6:
+profiles/r04_ab/frames_in_flight_final*.txt.  Twelve queues lose most of that again once the process has created and destroyed other
+renderers before -- the whole record: 8.6 Gray/s, and one-frame-at-a-time numbers up to 40 % worse -- so the default is 12 frames on 8
+queues: 9.0 Gray/s in the whole record; INTEGRATION.md tells a host how to set it).
 
   N = 1 : scenes/3d_room.json, 1920x1080, max depth 8 (BASELINE.json configs[1]).
   N > 1 : the frame grows with N (weak scaling: 1920x1080 pixels per GPU, aspect kept, same
@@ -68,8 +71,8 @@ def parse_args():
     ap.add_argument("--jit-flags", default=None, help="extra hiprtc flags for the specialised kernels (tuning experiments)")
     ap.add_argument("--renderer-flags", type=int, default=0, help="eu_renderer_opts.flags")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 8: measured "
-                         "5 / 8 / 12 in flight = 8.5 / 8.9 / 8.8 Gray/s on config 2 with 8 hardware queues, 8.0 / 8.2 / 8.4 with the runtime's 4; "
+                    help="frames traced concurrently, each by a renderer of its own on a stream of its own, one band stream each (0 = 12, on 8 hardware queues: the "
+                         "docstring has the sweep; round 3: 5 / 8 / 12 in flight = 8.5 / 8.9 / 8.8 Gray/s with 8 hardware queues, 8.0 / 8.2 / 8.4 with the runtime's 4; "
                          "1 = one frame at a time on two band streams)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps between two synchronisations) is run this many times; value and ms_per_step are the MEDIAN region, "
@@ -434,7 +437,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene)
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 8
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else 12
     band_streams = args.streams or (1 if in_flight > 1 else 0)      # frames in flight fill each other's kernel tails; a lone frame is cut into two bands for that
 
     def make_env(streams=None):
